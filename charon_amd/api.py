@@ -1,0 +1,285 @@
+"""ctypes binding of libcharon_hip.so (C ABI: include/charon_hip.h).
+
+There is no fallback path: if the library is missing this module raises at import, so a GPU test can
+never silently pass on CPU code.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcharon_hip.so")
+if not os.path.exists(LIB_PATH):
+    raise ImportError("charon_amd: %s not built -- run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+_L = C.CDLL(LIB_PATH)
+
+MINIMISER_SEED = 0x8F3F73B5CF1C9ADE
+STREAM_PROFILE = 1
+
+
+class IndexDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("kmer_size", C.c_uint8), ("window_size", C.c_uint8),
+                ("hash_funs", C.c_uint8), ("num_categories", C.c_uint8), ("host_index", C.c_uint8), ("reserved0", C.c_uint8 * 3),
+                ("minimiser_seed", C.c_uint64), ("bins", C.c_uint64), ("technical_bins", C.c_uint64), ("bin_size", C.c_uint64),
+                ("hash_shift", C.c_uint64), ("bin_words", C.c_uint64), ("bin_to_category", C.c_uint8 * 256),
+                ("row_begin", C.c_uint64), ("row_end", C.c_uint64)]
+
+
+class Model(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("num_categories", C.c_uint32), ("pos_data", C.POINTER(C.POINTER(C.c_float))),
+                ("pos_n", C.POINTER(C.c_uint32)), ("neg_data", C.POINTER(C.POINTER(C.c_float))), ("neg_n", C.POINTER(C.c_uint32)),
+                ("h_pos", C.c_float), ("h_neg", C.c_float), ("err_rate", C.c_float), ("min_quality", C.c_float),
+                ("min_length", C.c_uint32), ("min_compression", C.c_float), ("confidence_threshold", C.c_int8),
+                ("min_hits", C.c_uint8), ("paired", C.c_uint8), ("host_index", C.c_uint8),
+                ("confidence_probability_threshold", C.c_float), ("host_unique_prop_lo_threshold", C.c_float),
+                ("min_proportion_difference", C.c_float), ("min_prob_difference", C.c_float)]
+
+
+class StreamCfg(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("max_reads", C.c_uint64), ("max_bases", C.c_uint64)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("on_device", C.c_uint32), ("n_reads", C.c_uint64), ("n_bases", C.c_uint64),
+                ("bases2", C.c_void_p), ("nmask", C.c_void_p), ("seg1_offset", C.c_void_p), ("seg1_length", C.c_void_p),
+                ("seg2_offset", C.c_void_p), ("seg2_length", C.c_void_p), ("mean_quality", C.c_void_p),
+                ("compression", C.c_void_p)]
+
+
+class Result(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("on_device", C.c_uint32), ("num_hashes", C.c_void_p), ("counts", C.c_void_p),
+                ("unique_counts", C.c_void_p), ("probabilities", C.c_void_p), ("call", C.c_void_p), ("confidence", C.c_void_p),
+                ("flags", C.c_void_p)]
+
+
+class SynthReadsOut(C.Structure):
+    _fields_ = [("bases2", C.c_void_p), ("seg1_offset", C.c_void_p), ("seg1_length", C.c_void_p), ("mean_quality", C.c_void_p),
+                ("compression", C.c_void_p), ("n_bases", C.c_uint64)]
+
+
+# every symbol include/charon_hip.h declares
+EXPORTS = ["chn_index_create", "chn_index_upload_rows", "chn_index_device_words", "chn_index_download_rows",
+           "chn_index_get_desc", "chn_index_destroy", "chn_model_default", "chn_stream_create", "chn_stream_destroy",
+           "chn_model_set", "chn_batch_submit", "chn_batch_wait", "chn_stream_sync", "chn_stream_profile",
+           "chn_stream_last_batch_bytes", "chn_synth_genomes", "chn_synth_fill_index", "chn_synth_plant", "chn_synth_reads",
+           "chn_device_free", "chn_device_download", "chn_last_error", "chn_version"]
+
+_L.chn_last_error.restype = C.c_char_p
+_L.chn_version.restype = C.c_char_p
+_L.chn_index_create.argtypes = [C.POINTER(IndexDesc), C.POINTER(C.c_void_p)]
+_L.chn_index_upload_rows.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+_L.chn_index_download_rows.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+_L.chn_index_device_words.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+_L.chn_index_get_desc.argtypes = [C.c_void_p, C.POINTER(IndexDesc)]
+_L.chn_index_destroy.argtypes = [C.c_void_p]
+_L.chn_model_default.argtypes = [C.POINTER(Model), C.c_uint32, C.c_uint8, C.c_int]
+_L.chn_stream_create.argtypes = [C.c_void_p, C.POINTER(StreamCfg), C.POINTER(C.c_void_p)]
+_L.chn_stream_destroy.argtypes = [C.c_void_p]
+_L.chn_model_set.argtypes = [C.c_void_p, C.POINTER(Model)]
+_L.chn_batch_submit.argtypes = [C.c_void_p, C.POINTER(Batch)]
+_L.chn_batch_wait.argtypes = [C.c_void_p, C.POINTER(Result)]
+_L.chn_stream_sync.argtypes = [C.c_void_p]
+_L.chn_stream_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+_L.chn_stream_last_batch_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+_L.chn_synth_genomes.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
+_L.chn_synth_fill_index.argtypes = [C.c_void_p, C.c_uint64, C.c_double]
+_L.chn_synth_plant.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p]
+_L.chn_synth_reads.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
+                               C.c_double, C.c_double, C.c_float, C.POINTER(SynthReadsOut)]
+_L.chn_device_free.argtypes = [C.c_int, C.c_void_p]
+_L.chn_device_download.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
+
+
+class ChnError(RuntimeError):
+    pass
+
+
+def _chk(rc):
+    if rc != 0:
+        raise ChnError("libcharon_hip error %d: %s" % (rc, _L.chn_last_error().decode()))
+
+
+def lib():
+    return _L
+
+
+def version():
+    return _L.chn_version().decode()
+
+
+def clz64(x):
+    return 64 - int(x).bit_length()
+
+
+def make_desc(bins, bin_size, bin_to_cat, num_categories, host_index, k=19, w=41, hash_funs=3, device=0,
+              row_begin=0, row_end=0):
+    d = IndexDesc()
+    d.struct_size = C.sizeof(IndexDesc)
+    d.device = device
+    d.kmer_size, d.window_size, d.hash_funs = k, w, hash_funs
+    d.num_categories, d.host_index = num_categories, host_index
+    d.minimiser_seed = MINIMISER_SEED
+    d.bins = bins
+    d.bin_words = (bins + 63) // 64
+    d.technical_bins = d.bin_words * 64
+    d.bin_size = bin_size
+    d.hash_shift = clz64(bin_size)
+    for b in range(bins):
+        d.bin_to_category[b] = int(bin_to_cat[b])
+    d.row_begin, d.row_end = row_begin, row_end
+    return d
+
+
+class Index:
+    def __init__(self, desc):
+        self.desc = desc
+        self.h = C.c_void_p()
+        _chk(_L.chn_index_create(C.byref(desc), C.byref(self.h)))
+
+    @property
+    def device(self):
+        return self.desc.device
+
+    def upload(self, words, row_begin=0):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        n_rows = words.size // self.desc.bin_words
+        _chk(_L.chn_index_upload_rows(self.h, row_begin, n_rows, words.ctypes.data))
+
+    def download(self, row_begin=0, n_rows=None):
+        n_rows = self.desc.bin_size if n_rows is None else n_rows
+        out = np.zeros(n_rows * self.desc.bin_words, np.uint64)
+        _chk(_L.chn_index_download_rows(self.h, row_begin, n_rows, out.ctypes.data))
+        return out
+
+    def device_words(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        _chk(_L.chn_index_device_words(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def synth_fill(self, seed, density):
+        _chk(_L.chn_synth_fill_index(self.h, seed, density))
+
+    def synth_plant(self, dev_genomes, n_genomes, genome_len, genome_bin):
+        _chk(_L.chn_synth_plant(self.h, dev_genomes, n_genomes, genome_len, bytes(bytearray(int(b) for b in genome_bin))))
+
+    def destroy(self):
+        if self.h:
+            _L.chn_index_destroy(self.h)
+            self.h = None
+
+
+def default_model(num_categories, host_index, paired=False, **overrides):
+    m = Model()
+    _chk(_L.chn_model_default(C.byref(m), num_categories, host_index, 1 if paired else 0))
+    for k, v in overrides.items():
+        setattr(m, k, v)
+    return m
+
+
+class Stream:
+    def __init__(self, index, max_reads, max_bases, profile=False):
+        self.index = index
+        cfg = StreamCfg(C.sizeof(StreamCfg), STREAM_PROFILE if profile else 0, max_reads, max_bases)
+        self.h = C.c_void_p()
+        _chk(_L.chn_stream_create(index.h, C.byref(cfg), C.byref(self.h)))
+        self.C = index.desc.num_categories
+        self._keep = None
+
+    def set_model(self, model):
+        _chk(_L.chn_model_set(self.h, C.byref(model)))
+
+    def submit_host(self, packed, mean_quality=None, compression=None):
+        """packed: dict from charon_amd.pack.pack_reads"""
+        n = len(packed["seg1_length"])
+        b = Batch()
+        b.struct_size, b.on_device, b.n_reads, b.n_bases = C.sizeof(Batch), 0, n, packed["n_bases"]
+        keep = []
+
+        def ptr(a, dt):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=dt)
+            keep.append(a)
+            return a.ctypes.data
+
+        b.bases2 = ptr(packed["bases2"], np.uint32)
+        b.nmask = ptr(packed.get("nmask"), np.uint32)
+        b.seg1_offset = ptr(packed["seg1_offset"], np.uint64)
+        b.seg1_length = ptr(packed["seg1_length"], np.uint32)
+        b.seg2_offset = ptr(packed.get("seg2_offset"), np.uint64)
+        b.seg2_length = ptr(packed.get("seg2_length"), np.uint32)
+        b.mean_quality = ptr(mean_quality, np.float32)
+        b.compression = ptr(compression, np.float32)
+        self._keep = keep
+        self._n = n
+        _chk(_L.chn_batch_submit(self.h, C.byref(b)))
+
+    def submit_device(self, n_reads, n_bases, bases2, seg1_offset, seg1_length, mean_quality=None, compression=None,
+                      nmask=None, seg2_offset=None, seg2_length=None):
+        b = Batch()
+        b.struct_size, b.on_device, b.n_reads, b.n_bases = C.sizeof(Batch), 1, n_reads, n_bases
+        b.bases2, b.nmask, b.seg1_offset, b.seg1_length = bases2, nmask, seg1_offset, seg1_length
+        b.seg2_offset, b.seg2_length, b.mean_quality, b.compression = seg2_offset, seg2_length, mean_quality, compression
+        self._n = n_reads
+        _chk(_L.chn_batch_submit(self.h, C.byref(b)))
+
+    def wait_host(self):
+        n, Cn = self._n, self.C
+        out = dict(num_hashes=np.zeros(n, np.uint32), counts=np.zeros((n, Cn), np.uint32), unique=np.zeros((n, Cn), np.uint32),
+                   probs=np.zeros((n, Cn), np.float64), call=np.zeros(n, np.uint8), conf=np.zeros(n, np.uint8),
+                   flags=np.zeros(n, np.uint8))
+        r = Result(C.sizeof(Result), 0, out["num_hashes"].ctypes.data, out["counts"].ctypes.data, out["unique"].ctypes.data,
+                   out["probs"].ctypes.data, out["call"].ctypes.data, out["conf"].ctypes.data, out["flags"].ctypes.data)
+        _chk(_L.chn_batch_wait(self.h, C.byref(r)))
+        self._keep = None
+        return out
+
+    def wait_device(self):
+        r = Result()
+        r.struct_size, r.on_device = C.sizeof(Result), 1
+        _chk(_L.chn_batch_wait(self.h, C.byref(r)))
+        return r
+
+    def sync(self):
+        _chk(_L.chn_stream_sync(self.h))
+
+    def profile(self, which, reset=False):
+        ms, n = C.c_double(), C.c_uint64()
+        _chk(_L.chn_stream_profile(self.h, which, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
+    def last_batch_bytes(self):
+        b, m = C.c_uint64(), C.c_uint64()
+        _chk(_L.chn_stream_last_batch_bytes(self.h, C.byref(b), C.byref(m)))
+        return b.value, m.value
+
+    def destroy(self):
+        if self.h:
+            _L.chn_stream_destroy(self.h)
+            self.h = None
+
+
+def synth_genomes(device, seed, n_genomes, genome_len):
+    p = C.c_void_p()
+    _chk(_L.chn_synth_genomes(device, seed, n_genomes, genome_len, C.byref(p)))
+    return p.value
+
+
+def synth_reads(device, seed, dev_genomes, n_genomes, genome_len, n_reads, len_min, len_max, sub_rate=0.05,
+                random_fraction=0.1, mean_quality=40.0):
+    out = SynthReadsOut()
+    _chk(_L.chn_synth_reads(device, seed, dev_genomes, n_genomes, genome_len, n_reads, len_min, len_max, sub_rate,
+                            random_fraction, mean_quality, C.byref(out)))
+    return out
+
+
+def device_free(device, ptr):
+    if ptr:
+        _chk(_L.chn_device_free(device, ptr))
+
+
+def device_download(device, ptr, nbytes, dtype):
+    out = np.zeros(nbytes // np.dtype(dtype).itemsize, dtype)
+    _chk(_L.chn_device_download(device, out.ctypes.data, ptr, nbytes))
+    return out

@@ -1,0 +1,1255 @@
+// libcharon_hip.so -- MI355X (gfx950 / CDNA4) implementation of the per-read classification path of
+// `charon dehost` behind the C ABI of include/charon_hip.h.
+//
+// Kernel chain per batch (all on one HIP stream, no host round trip):
+//   k_len_bucket_*      order reads by length class so that a wavefront holds reads of similar length
+//   k_minimise_probe    ONE LANE PER READ: rolls the canonical base-5 k-mer hash (seqan3 minimiser_hash
+//                       semantics, src/dehost_main.cpp:317-318,367), runs the exact sequential window-minimum
+//                       emission rule (so ties/homopolymers are exact by construction), compacts emitted
+//                       minimisers of the 64 reads of the wavefront into an LDS queue, and every 64 queued
+//                       minimisers does one full-width probe round: 64 lanes x h gathers of W words from the
+//                       HBM-resident interleaved Bloom filter (bulk_contains, src/dehost_main.cpp:368), AND,
+//                       then either accumulates per-category hit / unique-hit counters in LDS (FUSED: every
+//                       category owns one bin, C <= 8) or appends the bit-row to the read's row list in HBM.
+//   k_count_rows        (general layouts) one wavefront per read: per-bin totals -> first max bin per
+//                       category -> unique hits  (ReadEntry::get_counts, include/read_entry.hpp:92-138)
+//   k_model_call        one lane per read: KDE/dexp probability + call_host / call_category
+//                       (include/classify_stats.hpp:242-252,370-389; include/read_entry.hpp:157-279)
+// No MFMA: the path is integer/bit work bound by random 8-16 byte gathers from HBM.
+//
+// This file is written for gfx950 only.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "charon_hip.h"
+#include "default_kde.inc"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess)                                                                                \
+            return fail(_e == hipErrorOutOfMemory ? CHN_E_NOMEM : CHN_E_HIP,                                 \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                                  \
+    } while (0)
+
+extern "C" const char *chn_last_error(void) { return g_err.c_str(); }
+extern "C" const char *chn_version(void) { return "charon_hip 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+#define WAVE 64
+#define QCAP 128  // LDS minimiser queue entries per wavefront (power of two, >= 2*WAVE)
+
+__device__ __constant__ uint64_t c_ibf_seeds[5] = {13572355802537770549ULL, 13043817825332782213ULL,
+                                                   10650232656628343401ULL, 16499269484942379435ULL,
+                                                   4893150838803335377ULL};
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (WAVE - 1); }
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint64_t t = (uint64_t)__shfl_xor((long long)v, o);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+// seqan3 interleaved_bloom_filter::hash_and_fit (fastrange), SURVEY App. A.3
+__device__ __forceinline__ uint64_t hash_and_fit_row(uint64_t x, uint64_t seed, uint64_t S, uint32_t shift) {
+    x *= seed;
+    x ^= x >> shift;
+    x *= 11400714819323198485ULL;
+    return __umul64hi(x, S);
+}
+
+// counter-based PRNG (splitmix64 finaliser) shared by the synthetic-workload kernels
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_minimise_probe
+// ------------------------------------------------------------------------------------------------
+enum { MODE_FUSED = 0, MODE_ROWS = 1, MODE_EMPLACE = 2 };
+
+struct K1Args {
+    const uint64_t *words;   // IBF shard, word (row - row_begin) * W + b
+    uint64_t *words_rw;      // MODE_EMPLACE
+    uint64_t S, row_begin, seed, powk1;
+    uint32_t shift, h, k, wn, n_reads, nseg, B, C;
+    uint64_t b2c_packed;     // MODE_FUSED: category of bin b in byte b
+    const uint32_t *bases, *nmask;
+    const uint64_t *off1, *off2;
+    const uint32_t *len1, *len2;
+    const uint32_t *order;
+    uint32_t *num_hashes, *counts, *unique;
+    uint64_t *rows;          // MODE_ROWS: row list of read r starts at row index off1[r]
+    const uint8_t *read_bin; // MODE_EMPLACE: target bin of "read" (genome chunk) r
+};
+
+template <int W>
+__device__ __forceinline__ void load_row_and(const uint64_t *p, uint64_t *acc) {
+    if (W == 1) {
+        acc[0] &= p[0];
+    } else if (W == 2) {
+        ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p);
+        acc[0] &= v.x; acc[1] &= v.y;
+    } else if (W == 3) {
+        acc[0] &= p[0]; acc[1] &= p[1]; acc[2] &= p[2];
+    } else {
+        ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(p);
+        ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(p + 2);
+        acc[0] &= a.x; acc[1] &= a.y; acc[2] &= b.x; acc[3] &= b.y;
+    }
+}
+
+template <int W, int MODE>
+__global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    // LDS carve-up (one wavefront per workgroup)
+    uint64_t *ring = reinterpret_cast<uint64_t *>(smem);                      // [wn][64] window values per lane
+    uint64_t *qv = ring + (size_t)a.wn * WAVE;                                // [QCAP] queued minimiser values
+    uint32_t *qm = reinterpret_cast<uint32_t *>(qv + QCAP);                   // [QCAP] owner lane | idx << 6
+    uint64_t *rbase = reinterpret_cast<uint64_t *>(qm + QCAP);                // [64] MODE_ROWS row base / EMPLACE bin
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(rbase + WAVE);               // MODE_FUSED [C][64]
+    uint32_t *unq = cnt + (MODE == MODE_FUSED ? a.C * WAVE : 0);              // MODE_FUSED [C][64]
+
+    const uint32_t lane = lane_id();
+    const uint32_t g = blockIdx.x * WAVE + lane;
+    const bool valid = g < a.n_reads;
+    const uint32_t r = valid ? (a.order ? a.order[g] : g) : 0;
+
+    if (MODE == MODE_FUSED)
+        for (uint32_t c = 0; c < a.C; ++c) { cnt[c * WAVE + lane] = 0; unq[c * WAVE + lane] = 0; }
+    if (MODE == MODE_ROWS) rbase[lane] = valid ? a.off1[r] : 0;
+    if (MODE == MODE_EMPLACE) rbase[lane] = valid ? a.read_bin[r] : 0;
+    __syncthreads();
+
+    const uint32_t k = a.k, wn = a.wn;
+    const uint64_t INV5 = 0xCCCCCCCCCCCCCCCDULL;  // 5^-1 mod 2^64 (exact division of the reverse strand)
+    uint32_t my_emitted = 0;                      // == ReadEntry::num_hashes_ (include/read_entry.hpp:89)
+    uint32_t qhead = 0, qcount = 0;               // wave-uniform queue state
+
+    auto probe_round = [&](uint32_t n_take) {
+        __syncthreads();
+        const bool has = lane < n_take;
+        const uint32_t slot = (qhead + lane) & (QCAP - 1);
+        const uint64_t val = qv[slot];
+        const uint32_t meta = qm[slot];
+        const uint32_t owner = meta & 63u, idx = meta >> 6;
+        if (MODE == MODE_EMPLACE) {
+            if (has) {
+                const uint32_t bin = (uint32_t)rbase[owner];
+                for (uint32_t i = 0; i < a.h; ++i) {
+                    uint64_t row = hash_and_fit_row(val, c_ibf_seeds[i], a.S, a.shift);
+                    atomicOr((unsigned long long *)&a.words_rw[(row - a.row_begin) * W + (bin >> 6)], 1ULL << (bin & 63));
+                }
+            }
+        } else {
+            uint64_t acc[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) acc[w] = ~0ULL;
+            if (has) {
+                uint64_t rows_[5];
+#pragma unroll
+                for (uint32_t i = 0; i < 5; ++i)
+                    if (i < a.h) rows_[i] = hash_and_fit_row(val, c_ibf_seeds[i], a.S, a.shift);
+#pragma unroll
+                for (uint32_t i = 0; i < 5; ++i)
+                    if (i < a.h) load_row_and<W>(a.words + (rows_[i] - a.row_begin) * W, acc);
+            }
+            if (MODE == MODE_FUSED) {
+                uint64_t m = has ? (acc[0] & ((a.B >= 64) ? ~0ULL : ((1ULL << a.B) - 1))) : 0;
+                const bool single = __popcll(m) == 1;
+                while (m) {
+                    const uint32_t b = (uint32_t)__ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const uint32_t c = (uint32_t)(a.b2c_packed >> (8 * b)) & 0xffu;
+                    atomicAdd(&cnt[c * WAVE + owner], 1u);
+                    if (single) atomicAdd(&unq[c * WAVE + owner], 1u);
+                }
+            } else {  // MODE_ROWS: append to the owner's row list (order inside a read is irrelevant to the counts)
+                if (has) {
+                    uint64_t *dst = a.rows + (rbase[owner] + idx) * W;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) dst[w] = acc[w];
+                }
+            }
+        }
+        qhead = (qhead + n_take) & (QCAP - 1);
+        qcount -= n_take;
+        __syncthreads();
+    };
+
+    for (uint32_t s = 0; s < a.nseg; ++s) {
+        const uint32_t L = valid ? (s == 0 ? a.len1[r] : a.len2[r]) : 0;
+        const uint64_t off = valid ? (s == 0 ? a.off1[r] : a.off2[r]) : 0;
+        const uint32_t maxL = wave_max_u32(L);
+        const uint32_t *bp = a.bases + (off >> 4);
+        const uint32_t *np = a.nmask ? a.nmask + (off >> 5) : nullptr;
+        uint64_t fwd = 0, rc = 0, hist2 = 0, mv = 0;
+        uint32_t histn = 0, cur = 0, ncur = 0, slot = 0, q = 0;
+
+        for (uint32_t i = 0; i < maxL; ++i) {
+            const bool act = i < L;
+            if ((i & 15u) == 0 && act) cur = bp[i >> 4];
+            if (np && (i & 31u) == 0 && act) ncur = np[i >> 5];
+            bool emit = false;
+            if (act) {
+                const uint32_t code = (cur >> ((i & 15u) * 2)) & 3u;
+                const uint32_t nf = np ? ((ncur >> (i & 31u)) & 1u) : 0u;
+                // dna5 ranks A0 C1 G2 N3 T4; complement table [4,2,1,3,0]
+                const uint32_t d_in = nf ? 3u : code + (code == 3u);
+                const uint32_t cd_in = nf ? 3u : (3u - code) + (code == 0u);
+                uint32_t d_out = 0, cd_out = 0;
+                if (i >= k) {
+                    const uint32_t oc = (uint32_t)(hist2 >> (2 * (k - 1))) & 3u;
+                    const uint32_t on = (histn >> (k - 1)) & 1u;
+                    d_out = on ? 3u : oc + (oc == 3u);
+                    cd_out = on ? 3u : (3u - oc) + (oc == 0u);
+                }
+                hist2 = (hist2 << 2) | code;
+                histn = (histn << 1) | nf;
+                fwd = (fwd - (uint64_t)d_out * a.powk1) * 5u + d_in;
+                rc = (rc - cd_out) * INV5 + (uint64_t)cd_in * a.powk1;
+                if (i + 1 >= k) {
+                    const uint32_t p = i + 1 - k;  // index of this canonical value
+                    const uint64_t vf = fwd ^ a.seed, vr = rc ^ a.seed;
+                    const uint64_t v = vf < vr ? vf : vr;
+                    ring[slot * WAVE + lane] = v;
+                    if (p < wn) {  // first window still filling: track the rightmost minimum
+                        if (p == 0 || v <= mv) { mv = v; q = p; }
+                        emit = (p == wn - 1);
+                    } else if (q + wn == p) {  // tracked minimum left the window: rightmost minimum of the new one
+                        uint32_t sl = slot + 1 == wn ? 0 : slot + 1;  // oldest value of the new window
+                        uint64_t best = ring[sl * WAVE + lane];
+                        uint32_t bq = p + 1 - wn;
+                        for (uint32_t t = 1; t < wn; ++t) {
+                            sl = sl + 1 == wn ? 0 : sl + 1;
+                            const uint64_t x = ring[sl * WAVE + lane];
+                            if (x <= best) { best = x; bq = p + 1 - wn + t; }
+                        }
+                        mv = best; q = bq; emit = true;
+                    } else if (v < mv) {
+                        mv = v; q = p; emit = true;
+                    }
+                    slot = slot + 1 == wn ? 0 : slot + 1;
+                    // sequence shorter than one window: a single minimiser over all its values
+                    if (i + 1 == L && p + 1 < wn) emit = true;
+                }
+            }
+            const uint64_t mask = __ballot(emit);
+            if (mask) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (emit) {
+                    const uint32_t pos = (qhead + qcount + rank) & (QCAP - 1);
+                    qv[pos] = mv;
+                    qm[pos] = lane | (my_emitted << 6);
+                    ++my_emitted;
+                }
+                qcount += (uint32_t)__popcll(mask);
+                if (qcount >= WAVE) probe_round(WAVE);
+            }
+        }
+    }
+    if (qcount) probe_round(qcount);
+
+    if (valid && MODE != MODE_EMPLACE) {
+        a.num_hashes[r] = my_emitted;
+        if (MODE == MODE_FUSED)
+            for (uint32_t c = 0; c < a.C; ++c) {
+                a.counts[(size_t)r * a.C + c] = cnt[c * WAVE + lane];
+                a.unique[(size_t)r * a.C + c] = unq[c * WAVE + lane];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_count_rows: ReadEntry::get_counts (include/read_entry.hpp:92-138) on the stored bit-rows
+// ------------------------------------------------------------------------------------------------
+struct K2Args {
+    const uint64_t *rows;
+    const uint64_t *off1;
+    const uint32_t *num_hashes;
+    uint32_t *counts, *unique;
+    uint32_t n_reads, B, C, W;
+    uint8_t b2c[256];
+};
+
+#define K2_WAVES 4
+template <int W>
+__global__ __launch_bounds__(WAVE *K2_WAVES) void k_count_rows(const K2Args a) {
+    __shared__ uint32_t s_tot[K2_WAVES][256];
+    __shared__ uint32_t s_unq[K2_WAVES][256];
+    __shared__ uint32_t s_chosen[K2_WAVES][256];
+    const uint32_t lane = lane_id(), wv = threadIdx.x / WAVE;
+    const uint32_t r = blockIdx.x * K2_WAVES + wv;
+    if (r >= a.n_reads) return;  // whole wavefront exits together; no block-wide barrier is used below
+    uint32_t *tot = s_tot[wv], *unq = s_unq[wv], *chosen = s_chosen[wv];
+    for (uint32_t b = lane; b < 256; b += WAVE) { tot[b] = 0; unq[b] = 0; chosen[b] = 255; }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t M = a.num_hashes[r];
+    const uint64_t *rows = a.rows + a.off1[r] * W;
+    // pass A: total_bits_per_bin (:96-99)
+    for (uint32_t m = lane; m < M; m += WAVE) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            uint64_t x = rows[(size_t)m * W + w];
+            if (w == W - 1 && (a.B & 63u)) x &= (1ULL << (a.B & 63u)) - 1;
+            while (x) {
+                const uint32_t b = (uint32_t)__ffsll((long long)x) - 1;
+                x &= x - 1;
+                atomicAdd(&tot[w * 64 + b], 1u);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    // first bin with the strictly largest total per category (:102-115): key = total << 8 | (255 - bin)
+    uint64_t cmask[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) cmask[w] = 0;
+    for (uint32_t c = 0; c < a.C; ++c) {
+        uint64_t key = 0;
+        for (uint32_t b = lane; b < a.B; b += WAVE)
+            if (a.b2c[b] == c) {
+                const uint64_t kk = ((uint64_t)tot[b] << 8) | (255u - b);
+                key = kk > key ? kk : key;
+            }
+        // an existing bin always has key >= 1 (bin <= 254), so best == 0 means the category owns no bin: it keeps
+        // index 255 and count 0, as index_per_category does in the reference
+        const uint64_t best = wave_max_u64(key);
+        const bool cat_has_bin = best != 0;
+        if (cat_has_bin) {
+            const uint32_t bin = 255u - (uint32_t)(best & 0xffu);
+            if (lane == 0) {
+                chosen[c] = bin;
+                a.counts[(size_t)r * a.C + c] = (uint32_t)(best >> 8);
+            }
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+                if ((bin >> 6) == (uint32_t)w) cmask[w] |= 1ULL << (bin & 63u);
+        } else if (lane == 0) {
+            a.counts[(size_t)r * a.C + c] = 0;
+        }
+    }
+    // pass B: a minimiser is a unique hit if exactly one category's chosen bin contains it (:121-136)
+    for (uint32_t m = lane; m < M; m += WAVE) {
+        uint32_t found = 0, fbin = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint64_t x = rows[(size_t)m * W + w] & cmask[w];
+            found += (uint32_t)__popcll(x);
+            if (x) fbin = w * 64 + (uint32_t)__ffsll((long long)x) - 1;
+        }
+        if (found == 1) atomicAdd(&unq[a.b2c[fbin]], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    for (uint32_t c = lane; c < a.C; c += WAVE) a.unique[(size_t)r * a.C + c] = unq[c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_model_call: apply_model + call_host / call_category
+// ------------------------------------------------------------------------------------------------
+struct K3Args {
+    const uint32_t *num_hashes, *counts, *unique;
+    const uint32_t *len1, *len2;
+    const float *mean_quality, *compression;
+    double *prob;
+    uint8_t *call, *conf, *flags;
+    const float *data;            // all KDE datasets back to back
+    uint32_t pos_off[8], pos_n[8], neg_off[8], neg_n[8];   // C <= 8 on the device path
+    uint32_t n_reads, C;
+    float h_pos, h_neg, log_rate, rate;
+    float min_quality, min_compression, cpt, lo_thr, min_pd, min_prd;
+    uint32_t min_length;
+    int32_t conf_thr;
+    uint32_t min_hits, paired, host_index;
+};
+
+__device__ __forceinline__ float kde_prob_dev(const float *data, uint32_t n, float h, float x) {
+    // KDEParams::prob / K (include/classify_stats.hpp:242-252): K evaluated in double, accumulated in float
+    float total = 0.0f;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float t = (x - data[i]) / h;
+        const double kd = exp(-((double)t * (double)t) / 2.0) / sqrt(2 * 3.141592653589793238463);
+        total += (float)kd;
+    }
+    return total / (h * (float)n);
+}
+
+__global__ __launch_bounds__(256) void k_model_call(const K3Args a) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_reads) return;
+    const uint32_t C = a.C;
+    const uint32_t nh = a.num_hashes[r];
+    double prob[8];
+    float props[8], uprops[8];
+    uint32_t cnts[8], uq[8];
+    for (uint32_t c = 0; c < C; ++c) {
+        cnts[c] = a.counts[(size_t)r * C + c];
+        uq[c] = a.unique[(size_t)r * C + c];
+        props[c] = (float)cnts[c] / (float)nh;   // get_proportions (include/read_entry.hpp:140-150)
+        uprops[c] = (float)uq[c] / (float)nh;
+        const float x = uprops[c];
+        // Model::prob (include/classify_stats.hpp:370-389)
+        float p_err;
+        if (x != x) p_err = x;
+        else if (x < 0.0f) p_err = 0.0f;
+        else p_err = (float)exp((double)(a.log_rate - a.rate * x));  // stats::dexp(x, 300) = exp(log(300) - 300 x)
+        float p_pos = kde_prob_dev(a.data + a.pos_off[c], a.pos_n[c], a.h_pos, x);
+        const float p_neg = kde_prob_dev(a.data + a.neg_off[c], a.neg_n[c], a.h_neg, x);
+        if (x == 1.0f) p_pos = 1.0f;
+        const float total = p_err + p_pos + p_neg;
+        prob[c] = (double)(p_pos / total);       // probabilities_ starts at 1 and is multiplied once (:56,277)
+        a.prob[(size_t)r * C + c] = prob[c];
+    }
+    const float mq = a.mean_quality ? a.mean_quality[r] : 0.0f;
+    const float comp = a.compression ? a.compression[r] : 0.0f;
+    const uint32_t length = a.len1[r] + (a.len2 ? a.len2[r] : 0u);
+    uint8_t call = 255, flag = 0;
+    uint32_t conf;
+    if (!a.paired) {
+        // call_host (include/read_entry.hpp:218-269)
+        const uint32_t host = a.host_index, other = 1u - host;
+        const double hu = uprops[host], ou = uprops[other], hp = prob[host], op = prob[other];
+        uint32_t first = host, second = other;
+        if (hu < ou) { first = other; second = host; }
+        const uint32_t raw = uq[first] - uq[second];
+        conf = raw > 255u ? 255u : raw;
+        const bool gate = !((int32_t)conf < a.conf_thr) && !(mq < a.min_quality) && !(length < a.min_length) &&
+                          !(comp < a.min_compression);
+        if (gate) {
+            const double dc = (double)conf;
+            if (hu > ou && hu - ou > a.min_pd && hp > op && hp - op > a.min_prd && fmax(hp * dc, dc) >= a.cpt)
+                call = (uint8_t)host;
+            else if (hu < a.lo_thr && hu < ou && ou - hu > a.min_pd && hp < op && op - hp > a.min_prd &&
+                     fmax(op * dc, dc) >= a.cpt)
+                call = (uint8_t)other;
+            const double scale = fmax(fabs(hp), fabs(op));
+            if (fabs(fabs(hp - op) - (double)a.min_prd) <= 2e-6 * fmax(scale, 1e-300)) flag = 1;
+            if (a.cpt > 0.0f && (fabs(fmax(hp * dc, dc) - a.cpt) <= 2e-6 * fmax(a.cpt, 1.0f) ||
+                                 fabs(fmax(op * dc, dc) - a.cpt) <= 2e-6 * fmax(a.cpt, 1.0f))) flag = 1;
+        }
+    } else {
+        // call_category (include/read_entry.hpp:157-216)
+        uint32_t first = 0, second = 1;
+        if (uq[second] > uq[first]) { first = 1; second = 0; }
+        for (uint32_t i = 2; i < C; ++i)
+            if (uq[i] > uq[second]) {
+                second = i;
+                if (uq[second] > uq[first]) { const uint32_t t = first; first = second; second = t; }
+            }
+        const uint32_t raw = uq[first] - uq[second];
+        conf = raw > 255u ? 255u : raw;
+        const bool gate = !(mq < a.min_quality) && !(length < a.min_length) && !(comp < a.min_compression);
+        if (gate) {
+            if (prob[second] == 0 && prob[first] > 0) call = (uint8_t)first;
+            else if ((int32_t)conf > a.conf_thr && prob[first] > prob[second]) call = (uint8_t)first;
+            if (cnts[second] > cnts[first] || cnts[first] - cnts[second] < a.min_hits) call = 255;
+            if (props[second] > props[first] || props[first] - props[second] < a.min_pd) call = 255;
+            const double scale = fmax(fabs(prob[first]), fabs(prob[second]));
+            if (fabs(prob[first] - prob[second]) <= 2e-6 * fmax(scale, 1e-300)) flag = 1;
+        }
+    }
+    a.call[r] = call;
+    a.conf[r] = (uint8_t)conf;
+    a.flags[r] = flag;
+}
+
+// ------------------------------------------------------------------------------------------------
+// length-class ordering (counting sort on an 8-steps-per-octave bucket of the total read length)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t len_bucket(uint32_t len) {
+    if (len < 8) return len;
+    const uint32_t e = 31u - (uint32_t)__clz((int)len);
+    return (e - 2) * 8 + ((len >> (e - 3)) & 7u);  // 8..247
+}
+__global__ void k_len_hist(const uint32_t *len1, const uint32_t *len2, uint32_t n, uint32_t *hist) {
+    __shared__ uint32_t sh[256];
+    sh[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        atomicAdd(&sh[len_bucket(len1[i] + (len2 ? len2[i] : 0u))], 1u);
+    __syncthreads();
+    if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+}
+__global__ void k_len_scan(uint32_t *hist /* in: counts, out: start cursor, longest bucket first */) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t run = 0;
+        for (int b = 255; b >= 0; --b) { const uint32_t c = hist[b]; hist[b] = run; run += c; }
+    }
+}
+__global__ void k_len_scatter(const uint32_t *len1, const uint32_t *len2, uint32_t n, uint32_t *cursor, uint32_t *order) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[atomicAdd(&cursor[len_bucket(len1[i] + (len2 ? len2[i] : 0u))], 1u)] = i;
+}
+
+// algorithmic bytes of a batch: sum ceil(L/4) + M*h*W*8 + (8 + 8C)
+__global__ void k_batch_bytes(const uint32_t *len1, const uint32_t *len2, const uint32_t *num_hashes, uint32_t n,
+                              uint32_t hW8, uint32_t outb, unsigned long long *acc /* [2]: bytes, minimisers */) {
+    unsigned long long b = 0, m = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t L = len1[i] + (len2 ? len2[i] : 0u);
+        b += (L + 3) / 4 + (unsigned long long)num_hashes[i] * hW8 + outb;
+        m += num_hashes[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) { b += __shfl_xor((long long)b, o); m += __shfl_xor((long long)m, o); }
+    if (lane_id() == 0) { atomicAdd(&acc[0], b); atomicAdd(&acc[1], m); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic workload kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void k_synth_genomes(uint32_t *out, uint64_t n_dwords, uint64_t seed) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_dwords; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = (uint32_t)mix64(seed ^ (i * 0xD1342543DE82EF95ULL));
+}
+__global__ void k_synth_fill(uint64_t *words, uint64_t n_rows, uint32_t W, uint32_t B, uint64_t seed, uint32_t thr16) {
+    // every bit of the user bins is set with probability thr16 / 65536 (four 16-bit lotteries per mix64)
+    const uint64_t n_words = n_rows * W;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t w = (uint32_t)(i % W);
+        uint64_t x = 0;
+        for (uint32_t j = 0; j < 16; ++j) {
+            const uint64_t z = mix64(seed ^ (i * 16 + j) * 0x9E3779B97F4A7C15ULL);
+            for (uint32_t t = 0; t < 4; ++t)
+                if (((z >> (16 * t)) & 0xffffu) < thr16) x |= 1ULL << (j * 4 + t);
+        }
+        const uint32_t lo = w * 64;
+        if (B < lo + 64) x &= (B <= lo) ? 0ULL : ((1ULL << (B - lo)) - 1);
+        words[i] = x;
+    }
+}
+struct SynthReadsArgs {
+    const uint32_t *genomes;
+    uint64_t n_genomes, genome_len, seed, n_reads;
+    uint32_t len_min, len_max, sub_thr32, rand_thr32;
+    uint32_t *bases;
+    const uint64_t *off;
+    const uint32_t *len;
+};
+__global__ void k_synth_read_layout(uint64_t seed, uint64_t n_reads, uint32_t len_min, uint32_t len_max, uint32_t *len) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i < n_reads) {
+        uint32_t L = len_min;
+        if (len_max > len_min) {  // log-uniform in [len_min, len_max]
+            const double u = (double)(mix64(seed ^ (i * 0xA24BAED4963EE407ULL)) >> 11) * (1.0 / 9007199254740992.0);
+            L = (uint32_t)(exp(log((double)len_min) + u * (log((double)len_max) - log((double)len_min))));
+            L = L < len_min ? len_min : (L > len_max ? len_max : L);
+        }
+        len[i] = L;
+    }
+}
+__global__ void k_synth_offsets(const uint32_t *len, uint64_t n_reads, uint64_t *off, uint64_t *total) {
+    // single-thread exclusive scan of padded lengths (synthetic fabrication only, not on the timed path)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint64_t run = 0;
+        for (uint64_t i = 0; i < n_reads; ++i) { off[i] = run; run += ((uint64_t)len[i] + 63) & ~63ULL; }
+        *total = run;
+    }
+}
+__global__ void k_synth_reads(const SynthReadsArgs a) {
+    // one thread per output dword (16 bases) of one read; grid.y = read chunks
+    const uint64_t read = blockIdx.y + (uint64_t)blockIdx.z * gridDim.y;
+    if (read >= a.n_reads) return;
+    const uint32_t L = a.len[read];
+    const uint32_t nd = (L + 63) / 64 * 4;
+    const uint64_t rs = mix64(a.seed ^ (read * 0x9FB21C651E98DF25ULL));
+    const bool is_random = a.n_genomes == 0 || (uint32_t)(rs >> 32) < a.rand_thr32;
+    const uint64_t g = a.n_genomes ? (mix64(rs + 1) % a.n_genomes) : 0;
+    const uint64_t span = a.genome_len > L ? a.genome_len - L : 1;
+    const uint64_t start = mix64(rs + 2) % span;
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < nd; d += gridDim.x * blockDim.x) {
+        uint32_t out = 0;
+        for (uint32_t j = 0; j < 16; ++j) {
+            const uint32_t pos = d * 16 + j;
+            if (pos >= L) break;
+            const uint64_t z = mix64(rs ^ ((uint64_t)pos * 0xC2B2AE3D27D4EB4FULL));
+            uint32_t code;
+            if (is_random) code = (uint32_t)z & 3u;
+            else {
+                const uint64_t gp = g * a.genome_len + start + pos;
+                code = (a.genomes[gp >> 4] >> ((gp & 15) * 2)) & 3u;
+                if ((uint32_t)(z >> 32) < a.sub_thr32) code = (code + 1 + (uint32_t)(z % 3)) & 3u;  // uniform other base
+            }
+            out |= code << (2 * j);
+        }
+        a.bases[(a.off[read] >> 4) + d] = out;
+    }
+}
+__global__ void k_fill_f32(float *p, uint64_t n, float v) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void k_chunk_layout(uint64_t n_genomes, uint64_t genome_len, uint32_t chunk, uint32_t overlap, uint64_t chunks_per_genome,
+                               uint64_t *off, uint32_t *len) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n_genomes * chunks_per_genome) return;
+    const uint64_t g = i / chunks_per_genome, c = i % chunks_per_genome;
+    const uint64_t start = c * chunk;  // multiple of 64
+    const uint64_t end = (start + chunk + overlap < genome_len) ? start + chunk + overlap : genome_len;
+    off[i] = g * genome_len + start;
+    len[i] = (uint32_t)(end - start);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host objects
+// ------------------------------------------------------------------------------------------------
+struct chn_index {
+    chn_index_desc d;
+    uint64_t *words = nullptr;
+    uint64_t rows_local = 0;
+    bool single_bin_categories = false;  // every category owns exactly one bin
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return CHN_OK;
+        if (p) { HIPCHK(hipFree(p)); p = nullptr; cap = 0; }
+        HIPCHK(hipMalloc(&p, bytes));
+        cap = bytes;
+        return CHN_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+struct HostModel {  // deep copy of chn_model
+    bool set = false;
+    uint32_t C = 0;
+    std::vector<std::vector<float>> pos, neg;
+    float h_pos = 0.1f, h_neg = 0.001f, rate = 300.0f;
+    float min_quality = 15.0f, min_compression = 0, cpt = 0, lo_thr = 0.05f, min_pd = 0.04f, min_prd = 0;
+    uint32_t min_length = 140;
+    int8_t conf_thr = 7;
+    uint8_t min_hits = 0, paired = 0, host_index = 0;
+};
+
+struct chn_stream {
+    chn_index *idx = nullptr;
+    chn_stream_cfg cfg;
+    hipStream_t stream = nullptr;
+    // staging of host batches
+    DevBuf d_bases, d_nmask, d_off1, d_off2, d_len1, d_len2, d_mq, d_comp;
+    // per-batch device state
+    DevBuf d_order, d_hist, d_num_hashes, d_counts, d_unique, d_prob, d_call, d_conf, d_flags, d_rows, d_model, d_acc;
+    // current batch view (device pointers)
+    const uint32_t *bases = nullptr, *nmask = nullptr, *len1 = nullptr, *len2 = nullptr;
+    const uint64_t *off1 = nullptr, *off2 = nullptr;
+    const float *mq = nullptr, *comp = nullptr;
+    uint64_t n_reads = 0, n_bases = 0;
+    bool submitted = false;
+    HostModel model;
+    K3Args k3;
+    // host copies for the borderline re-evaluation
+    std::vector<uint32_t> h_len1, h_len2;
+    std::vector<float> h_mq, h_comp;
+    bool host_batch = false;
+    // profiling
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_used[4] = {false, false, false, false};
+    double prof_ms[4] = {0, 0, 0, 0};
+    uint64_t prof_n[4] = {0, 0, 0, 0};
+    uint64_t last_bytes = 0, last_min = 0;
+};
+
+static uint64_t pow5(unsigned e) { uint64_t p = 1; while (e--) p *= 5; return p; }
+
+extern "C" int chn_index_create(const chn_index_desc *desc, chn_index **out) {
+    if (!desc || !out || desc->struct_size != sizeof(chn_index_desc)) return fail(CHN_E_INVALID, "chn_index_create: bad descriptor");
+    const chn_index_desc &d = *desc;
+    if (d.kmer_size < 1 || d.kmer_size > 27) return fail(CHN_E_INVALID, "kmer_size must be in 1..27 (5^k has to fit 64 bits)");
+    if (d.window_size < d.kmer_size) return fail(CHN_E_INVALID, "window_size must be >= kmer_size");
+    if (d.hash_funs < 1 || d.hash_funs > 5) return fail(CHN_E_INVALID, "hash_funs must be in 1..5");
+    if (d.bins < 1 || d.bins > 255 || d.technical_bins != ((d.bins + 63) / 64) * 64 || d.bin_words != d.technical_bins / 64)
+        return fail(CHN_E_INVALID, "IBF header inconsistent: technical_bins must be 64*ceil(bins/64), bin_words = technical_bins/64");
+    if (d.bin_size == 0 || d.hash_shift != (uint64_t)__builtin_clzll(d.bin_size)) return fail(CHN_E_INVALID, "hash_shift must be countl_zero(bin_size)");
+    if (d.num_categories < 1) return fail(CHN_E_INVALID, "num_categories must be >= 1");
+    for (uint64_t b = 0; b < d.bins; ++b)
+        if (d.bin_to_category[b] >= d.num_categories) return fail(CHN_E_INVALID, "bin_to_category entry out of range");
+    chn_index *idx = new (std::nothrow) chn_index();
+    if (!idx) return fail(CHN_E_NOMEM, "host allocation failed");
+    idx->d = d;
+    if (idx->d.row_begin == 0 && idx->d.row_end == 0) idx->d.row_end = d.bin_size;
+    if (idx->d.row_end > d.bin_size || idx->d.row_begin >= idx->d.row_end) { delete idx; return fail(CHN_E_INVALID, "bad row shard"); }
+    idx->rows_local = idx->d.row_end - idx->d.row_begin;
+    std::vector<int> per_cat(d.num_categories, 0);
+    for (uint64_t b = 0; b < d.bins; ++b) per_cat[d.bin_to_category[b]]++;
+    idx->single_bin_categories = true;
+    for (int c : per_cat) if (c != 1) idx->single_bin_categories = false;
+    hipError_t e = hipSetDevice(d.device);
+    if (e == hipSuccess) e = hipMalloc((void **)&idx->words, idx->rows_local * d.bin_words * 8);
+    if (e != hipSuccess) { delete idx; return fail(e == hipErrorOutOfMemory ? CHN_E_NOMEM : CHN_E_HIP, std::string("index allocation: ") + hipGetErrorString(e)); }
+    e = hipMemset(idx->words, 0, idx->rows_local * d.bin_words * 8);
+    if (e != hipSuccess) { (void)hipFree(idx->words); delete idx; return fail(CHN_E_HIP, std::string("index memset: ") + hipGetErrorString(e)); }
+    *out = idx;
+    return CHN_OK;
+}
+
+extern "C" int chn_index_upload_rows(chn_index *idx, uint64_t row_begin, uint64_t n_rows, const uint64_t *host_words) {
+    if (!idx || !host_words) return fail(CHN_E_INVALID, "chn_index_upload_rows: null argument");
+    if (row_begin < idx->d.row_begin || row_begin + n_rows > idx->d.row_end) return fail(CHN_E_INVALID, "rows outside this shard");
+    HIPCHK(hipSetDevice(idx->d.device));
+    HIPCHK(hipMemcpy(idx->words + (row_begin - idx->d.row_begin) * idx->d.bin_words, host_words, n_rows * idx->d.bin_words * 8, hipMemcpyHostToDevice));
+    return CHN_OK;
+}
+extern "C" int chn_index_download_rows(chn_index *idx, uint64_t row_begin, uint64_t n_rows, uint64_t *host_words) {
+    if (!idx || !host_words) return fail(CHN_E_INVALID, "chn_index_download_rows: null argument");
+    if (row_begin < idx->d.row_begin || row_begin + n_rows > idx->d.row_end) return fail(CHN_E_INVALID, "rows outside this shard");
+    HIPCHK(hipSetDevice(idx->d.device));
+    HIPCHK(hipMemcpy(host_words, idx->words + (row_begin - idx->d.row_begin) * idx->d.bin_words, n_rows * idx->d.bin_words * 8, hipMemcpyDeviceToHost));
+    return CHN_OK;
+}
+extern "C" int chn_index_device_words(chn_index *idx, uint64_t **device_words, uint64_t *n_words) {
+    if (!idx) return fail(CHN_E_INVALID, "null index");
+    if (device_words) *device_words = idx->words;
+    if (n_words) *n_words = idx->rows_local * idx->d.bin_words;
+    return CHN_OK;
+}
+extern "C" int chn_index_get_desc(const chn_index *idx, chn_index_desc *out) {
+    if (!idx || !out) return fail(CHN_E_INVALID, "null argument");
+    *out = idx->d;
+    return CHN_OK;
+}
+extern "C" int chn_index_destroy(chn_index *idx) {
+    if (!idx) return CHN_OK;
+    (void)hipSetDevice(idx->d.device);
+    if (idx->words) (void)hipFree(idx->words);
+    delete idx;
+    return CHN_OK;
+}
+
+// ---- model --------------------------------------------------------------------------------------
+static std::vector<float> g_def_pos, g_def_neg;
+static const float *g_def_pos_ptr[CHN_MAX_CATEGORIES], *g_def_neg_ptr[CHN_MAX_CATEGORIES];
+static uint32_t g_def_n_pos[CHN_MAX_CATEGORIES], g_def_n_neg[CHN_MAX_CATEGORIES];
+
+extern "C" int chn_model_default(chn_model *m, uint32_t num_categories, uint8_t host_index, int paired) {
+    if (!m || num_categories < 1 || num_categories > CHN_MAX_CATEGORIES) return fail(CHN_E_INVALID, "chn_model_default: bad argument");
+    if (g_def_pos.empty()) {
+        for (double v : CHN_DEFAULT_POS) g_def_pos.push_back((float)v);
+        for (double v : CHN_DEFAULT_NEG) g_def_neg.push_back((float)v);
+        std::sort(g_def_pos.begin(), g_def_pos.end());  // KDEParams constructor sorts (include/classify_stats.hpp:214-218)
+        std::sort(g_def_neg.begin(), g_def_neg.end());
+    }
+    for (uint32_t c = 0; c < num_categories; ++c) {
+        g_def_pos_ptr[c] = g_def_pos.data(); g_def_neg_ptr[c] = g_def_neg.data();
+        g_def_n_pos[c] = (uint32_t)g_def_pos.size(); g_def_n_neg[c] = (uint32_t)g_def_neg.size();
+    }
+    std::memset(m, 0, sizeof(*m));
+    m->struct_size = sizeof(chn_model);
+    m->num_categories = num_categories;
+    m->pos_data = g_def_pos_ptr; m->pos_n = g_def_n_pos; m->neg_data = g_def_neg_ptr; m->neg_n = g_def_n_neg;
+    m->h_pos = 0.1f; m->h_neg = 0.001f; m->err_rate = 300.0f;
+    m->min_quality = 15.0f; m->min_length = paired ? 80 : 140; m->min_compression = 0.0f;
+    m->confidence_threshold = 7; m->min_hits = 0; m->paired = paired ? 1 : 0; m->host_index = host_index;
+    m->confidence_probability_threshold = 0.0f; m->host_unique_prop_lo_threshold = 0.05f;
+    m->min_proportion_difference = 0.04f; m->min_prob_difference = 0.0f;
+    return CHN_OK;
+}
+
+// host restatement of the model + call used to re-evaluate reads the device flags as borderline
+static float host_kde_prob(const std::vector<float> &data, float h, float x) {
+    float total = 0.0f;
+    for (float xi : data) {
+        const float t = (x - xi) / h;
+        total += (float)(std::exp(-std::pow((double)t, 2) / 2) / std::sqrt(2 * 3.141592653589793238463));
+    }
+    return total / (h * (float)data.size());
+}
+static void host_model_call(const HostModel &M, uint32_t nh, const uint32_t *cnts, const uint32_t *uq, float mq, float comp,
+                            uint32_t length, double *prob, uint8_t *call_out, uint8_t *conf_out) {
+    const uint32_t C = M.C;
+    std::vector<float> props(C), uprops(C);
+    for (uint32_t c = 0; c < C; ++c) {
+        props[c] = (float)cnts[c] / (float)nh;
+        uprops[c] = (float)uq[c] / (float)nh;
+        const float x = uprops[c];
+        float p_err;
+        if (std::isnan(x)) p_err = x; else if (x < 0.0f) p_err = 0.0f; else p_err = std::exp(std::log(M.rate) - M.rate * x);
+        float p_pos = host_kde_prob(M.pos[c], M.h_pos, x);
+        const float p_neg = host_kde_prob(M.neg[c], M.h_neg, x);
+        if (x == 1.0f) p_pos = 1.0f;
+        const float total = p_err + p_pos + p_neg;
+        prob[c] = (double)(p_pos / total);
+    }
+    uint8_t call = 255; uint32_t conf;
+    if (!M.paired) {
+        const uint32_t host = M.host_index, other = 1u - host;
+        const double hu = uprops[host], ou = uprops[other], hp = prob[host], op = prob[other];
+        uint32_t first = host, second = other;
+        if (hu < ou) { first = other; second = host; }
+        const uint32_t raw = uq[first] - uq[second];
+        conf = raw > 255u ? 255u : raw;
+        if (!((int)conf < (int)M.conf_thr) && !(mq < M.min_quality) && !(length < M.min_length) && !(comp < M.min_compression)) {
+            const double dc = (double)conf;
+            if (hu > ou && hu - ou > M.min_pd && hp > op && hp - op > M.min_prd && std::max(hp * dc, dc) >= M.cpt) call = (uint8_t)host;
+            else if (hu < M.lo_thr && hu < ou && ou - hu > M.min_pd && hp < op && op - hp > M.min_prd && std::max(op * dc, dc) >= M.cpt) call = (uint8_t)other;
+        }
+    } else {
+        uint32_t first = 0, second = 1;
+        if (uq[second] > uq[first]) std::swap(first, second);
+        for (uint32_t i = 2; i < C; ++i)
+            if (uq[i] > uq[second]) { second = i; if (uq[second] > uq[first]) std::swap(first, second); }
+        const uint32_t raw = uq[first] - uq[second];
+        conf = raw > 255u ? 255u : raw;
+        if (!(mq < M.min_quality) && !(length < M.min_length) && !(comp < M.min_compression)) {
+            if (prob[second] == 0 && prob[first] > 0) call = (uint8_t)first;
+            else if ((int)conf > (int)M.conf_thr && prob[first] > prob[second]) call = (uint8_t)first;
+            if (cnts[second] > cnts[first] || cnts[first] - cnts[second] < M.min_hits) call = 255;
+            if (props[second] > props[first] || props[first] - props[second] < M.min_pd) call = 255;
+        }
+    }
+    *call_out = call; *conf_out = (uint8_t)conf;
+}
+
+// ---- stream -------------------------------------------------------------------------------------
+extern "C" int chn_stream_create(chn_index *idx, const chn_stream_cfg *cfg, chn_stream **out) {
+    if (!idx || !cfg || !out || cfg->struct_size != sizeof(chn_stream_cfg)) return fail(CHN_E_INVALID, "chn_stream_create: bad argument");
+    if (cfg->max_reads == 0 || cfg->max_reads > 0xFFFFFF00ULL) return fail(CHN_E_INVALID, "max_reads out of range");
+    if (idx->d.row_begin != 0 || idx->d.row_end != idx->d.bin_size)
+        return fail(CHN_E_INVALID, "a classification stream needs an index object holding all rows (row-sharded objects are probe-only)");
+    HIPCHK(hipSetDevice(idx->d.device));
+    chn_stream *s = new (std::nothrow) chn_stream();
+    if (!s) return fail(CHN_E_NOMEM, "host allocation failed");
+    s->idx = idx; s->cfg = *cfg;
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete s; return fail(CHN_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    for (int i = 0; i < 8; ++i) {
+        e = hipEventCreate(&s->ev[i]);
+        if (e != hipSuccess) { delete s; return fail(CHN_E_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
+    }
+    const uint64_t n = cfg->max_reads, C = idx->d.num_categories;
+    int rc = CHN_OK;
+    if ((rc = s->d_order.ensure(n * 4)) || (rc = s->d_hist.ensure(256 * 4)) || (rc = s->d_num_hashes.ensure(n * 4)) ||
+        (rc = s->d_counts.ensure(n * C * 4)) || (rc = s->d_unique.ensure(n * C * 4)) || (rc = s->d_prob.ensure(n * C * 8)) ||
+        (rc = s->d_call.ensure(n)) || (rc = s->d_conf.ensure(n)) || (rc = s->d_flags.ensure(n)) || (rc = s->d_acc.ensure(16))) {
+        chn_stream_destroy(s);
+        return rc;
+    }
+    const bool fused = idx->single_bin_categories && C <= 8 && idx->d.bin_words == 1;
+    if (!fused) {
+        if ((rc = s->d_rows.ensure(cfg->max_bases * idx->d.bin_words * 8))) { chn_stream_destroy(s); return rc; }
+    }
+    *out = s;
+    return CHN_OK;
+}
+
+extern "C" int chn_stream_destroy(chn_stream *s) {
+    if (!s) return CHN_OK;
+    (void)hipSetDevice(s->idx->d.device);
+    if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+    for (int i = 0; i < 8; ++i) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
+    DevBuf *bufs[] = {&s->d_bases, &s->d_nmask, &s->d_off1, &s->d_off2, &s->d_len1, &s->d_len2, &s->d_mq, &s->d_comp, &s->d_order,
+                      &s->d_hist, &s->d_num_hashes, &s->d_counts, &s->d_unique, &s->d_prob, &s->d_call, &s->d_conf, &s->d_flags,
+                      &s->d_rows, &s->d_model, &s->d_acc};
+    for (DevBuf *b : bufs) b->release();
+    delete s;
+    return CHN_OK;
+}
+
+extern "C" int chn_model_set(chn_stream *s, const chn_model *m) {
+    if (!s || !m || m->struct_size != sizeof(chn_model)) return fail(CHN_E_INVALID, "chn_model_set: bad argument");
+    const uint32_t C = m->num_categories;
+    if (C != s->idx->d.num_categories) return fail(CHN_E_INVALID, "model category count differs from the index");
+    if (C > 8) return fail(CHN_E_INVALID, "the device model+call kernel supports at most 8 categories");
+    if (!m->paired && (C < 2 || m->host_index > 1))
+        return fail(CHN_E_INVALID, "single-end dehost (call_host) needs the host category at index 0 or 1 of a >= 2 category index");
+    if (m->paired && C < 2) return fail(CHN_E_INVALID, "call_category needs at least 2 categories");
+    HIPCHK(hipSetDevice(s->idx->d.device));
+    HostModel &M = s->model;
+    M = HostModel();
+    M.C = C;
+    size_t total = 0;
+    for (uint32_t c = 0; c < C; ++c) {
+        if (!m->pos_data[c] || !m->neg_data[c]) return fail(CHN_E_INVALID, "null KDE dataset");
+        M.pos.emplace_back(m->pos_data[c], m->pos_data[c] + m->pos_n[c]);
+        M.neg.emplace_back(m->neg_data[c], m->neg_data[c] + m->neg_n[c]);
+        total += m->pos_n[c] + m->neg_n[c];
+    }
+    M.h_pos = m->h_pos; M.h_neg = m->h_neg; M.rate = m->err_rate;
+    M.min_quality = m->min_quality; M.min_length = m->min_length; M.min_compression = m->min_compression;
+    M.conf_thr = m->confidence_threshold; M.min_hits = m->min_hits; M.paired = m->paired; M.host_index = m->host_index;
+    M.cpt = m->confidence_probability_threshold; M.lo_thr = m->host_unique_prop_lo_threshold;
+    M.min_pd = m->min_proportion_difference; M.min_prd = m->min_prob_difference;
+    std::vector<float> flat;
+    flat.reserve(total);
+    K3Args &k = s->k3;
+    std::memset(&k, 0, sizeof(k));
+    for (uint32_t c = 0; c < C; ++c) {
+        k.pos_off[c] = (uint32_t)flat.size(); k.pos_n[c] = (uint32_t)M.pos[c].size();
+        flat.insert(flat.end(), M.pos[c].begin(), M.pos[c].end());
+        k.neg_off[c] = (uint32_t)flat.size(); k.neg_n[c] = (uint32_t)M.neg[c].size();
+        flat.insert(flat.end(), M.neg[c].begin(), M.neg[c].end());
+    }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    int rc = s->d_model.ensure(std::max<size_t>(flat.size() * 4, 4));
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(s->d_model.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
+    k.data = s->d_model.as<float>();
+    k.C = C; k.h_pos = M.h_pos; k.h_neg = M.h_neg; k.rate = M.rate; k.log_rate = std::log(M.rate);
+    k.min_quality = M.min_quality; k.min_compression = M.min_compression; k.cpt = M.cpt; k.lo_thr = M.lo_thr;
+    k.min_pd = M.min_pd; k.min_prd = M.min_prd; k.min_length = M.min_length; k.conf_thr = (int32_t)M.conf_thr;
+    k.min_hits = M.min_hits; k.paired = M.paired; k.host_index = M.host_index;
+    M.set = true;
+    return CHN_OK;
+}
+
+template <int W, int MODE>
+static hipError_t launch_k1(const K1Args &a, size_t lds, hipStream_t st) {
+    const uint32_t blocks = (a.n_reads + WAVE - 1) / WAVE;
+    hipLaunchKernelGGL((k_minimise_probe<W, MODE>), dim3(blocks), dim3(WAVE), lds, st, a);
+    return hipGetLastError();
+}
+template <int MODE>
+static hipError_t launch_k1_w(uint32_t W, const K1Args &a, size_t lds, hipStream_t st) {
+    switch (W) {
+        case 1: return launch_k1<1, MODE>(a, lds, st);
+        case 2: return launch_k1<2, MODE>(a, lds, st);
+        case 3: return launch_k1<3, MODE>(a, lds, st);
+        default: return launch_k1<4, MODE>(a, lds, st);
+    }
+}
+static size_t k1_lds_bytes(uint32_t wn, uint32_t C, int mode) {
+    size_t b = (size_t)wn * WAVE * 8 + QCAP * 8 + QCAP * 4 + WAVE * 8;
+    if (mode == MODE_FUSED) b += (size_t)2 * C * WAVE * 4;
+    return b;
+}
+
+static int upload(DevBuf &buf, const void *src, size_t bytes, hipStream_t st) {
+    int rc = buf.ensure(std::max<size_t>(bytes, 16));
+    if (rc) return rc;
+    if (bytes) HIPCHK(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, st));
+    return CHN_OK;
+}
+
+extern "C" int chn_batch_submit(chn_stream *s, const chn_batch *b) {
+    if (!s || !b || b->struct_size != sizeof(chn_batch)) return fail(CHN_E_INVALID, "chn_batch_submit: bad argument");
+    if (s->submitted) return fail(CHN_E_STATE, "previous batch not waited for");
+    if (b->n_reads == 0) return fail(CHN_E_INVALID, "empty batch");
+    if (b->n_reads > s->cfg.max_reads || b->n_bases > s->cfg.max_bases) return fail(CHN_E_CAPACITY, "batch exceeds stream capacity");
+    if (!b->bases2 || !b->seg1_offset || !b->seg1_length) return fail(CHN_E_INVALID, "missing batch arrays");
+    if ((b->seg2_offset == nullptr) != (b->seg2_length == nullptr)) return fail(CHN_E_INVALID, "seg2_offset/seg2_length must both be set or both NULL");
+    if (b->n_bases % 64) return fail(CHN_E_INVALID, "n_bases must be a multiple of 64");
+    const chn_index_desc &d = s->idx->d;
+    HIPCHK(hipSetDevice(d.device));
+    const uint64_t n = b->n_reads;
+    const bool paired = b->seg2_offset != nullptr;
+    const uint32_t W = (uint32_t)d.bin_words, C = d.num_categories;
+    const bool fused = s->idx->single_bin_categories && C <= 8 && W == 1;
+    s->host_batch = !b->on_device;
+    if (!b->on_device) {
+        // host-side validation of operand shapes before anything is launched
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint64_t o1 = b->seg1_offset[i], l1 = b->seg1_length[i];
+            if ((o1 & 63) || o1 + l1 > b->n_bases) return fail(CHN_E_INVALID, "segment 1 of read " + std::to_string(i) + " is misaligned or out of range");
+            if (paired) {
+                const uint64_t o2 = b->seg2_offset[i], l2 = b->seg2_length[i];
+                if ((o2 & 63) || o2 + l2 > b->n_bases) return fail(CHN_E_INVALID, "segment 2 of read " + std::to_string(i) + " is misaligned or out of range");
+                if (!fused && o2 != ((o1 + l1 + 63) & ~63ULL)) return fail(CHN_E_INVALID, "paired batches need mate 2 stored directly after mate 1 (64-base padded)");
+            }
+        }
+        int rc;
+        if ((rc = upload(s->d_bases, b->bases2, b->n_bases / 4, s->stream))) return rc;
+        if (b->nmask && (rc = upload(s->d_nmask, b->nmask, b->n_bases / 8, s->stream))) return rc;
+        if ((rc = upload(s->d_off1, b->seg1_offset, n * 8, s->stream)) || (rc = upload(s->d_len1, b->seg1_length, n * 4, s->stream))) return rc;
+        if (paired && ((rc = upload(s->d_off2, b->seg2_offset, n * 8, s->stream)) || (rc = upload(s->d_len2, b->seg2_length, n * 4, s->stream)))) return rc;
+        if (b->mean_quality && (rc = upload(s->d_mq, b->mean_quality, n * 4, s->stream))) return rc;
+        if (b->compression && (rc = upload(s->d_comp, b->compression, n * 4, s->stream))) return rc;
+        s->bases = s->d_bases.as<uint32_t>();
+        s->nmask = b->nmask ? s->d_nmask.as<uint32_t>() : nullptr;
+        s->off1 = s->d_off1.as<uint64_t>(); s->len1 = s->d_len1.as<uint32_t>();
+        s->off2 = paired ? s->d_off2.as<uint64_t>() : nullptr; s->len2 = paired ? s->d_len2.as<uint32_t>() : nullptr;
+        s->mq = b->mean_quality ? s->d_mq.as<float>() : nullptr;
+        s->comp = b->compression ? s->d_comp.as<float>() : nullptr;
+        s->h_len1.assign(b->seg1_length, b->seg1_length + n);
+        if (paired) s->h_len2.assign(b->seg2_length, b->seg2_length + n); else s->h_len2.clear();
+        if (b->mean_quality) s->h_mq.assign(b->mean_quality, b->mean_quality + n); else s->h_mq.clear();
+        if (b->compression) s->h_comp.assign(b->compression, b->compression + n); else s->h_comp.clear();
+    } else {
+        s->bases = b->bases2; s->nmask = b->nmask; s->off1 = b->seg1_offset; s->len1 = b->seg1_length;
+        s->off2 = b->seg2_offset; s->len2 = b->seg2_length; s->mq = b->mean_quality; s->comp = b->compression;
+    }
+    s->n_reads = n; s->n_bases = b->n_bases;
+    const bool prof = (s->cfg.flags & CHN_STREAM_PROFILE) != 0;
+    for (int i = 0; i < 4; ++i) s->ev_used[i] = false;
+    if (prof) HIPCHK(hipEventRecord(s->ev[6], s->stream));
+
+    // 1. length-class ordering
+    HIPCHK(hipMemsetAsync(s->d_hist.p, 0, 256 * 4, s->stream));
+    hipLaunchKernelGGL(k_len_hist, dim3(std::min<uint64_t>(1024, (n + 255) / 256)), dim3(256), 0, s->stream, s->len1, s->len2, (uint32_t)n, s->d_hist.as<uint32_t>());
+    hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(64), 0, s->stream, s->d_hist.as<uint32_t>());
+    hipLaunchKernelGGL(k_len_scatter, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->len1, s->len2, (uint32_t)n, s->d_hist.as<uint32_t>(), s->d_order.as<uint32_t>());
+    HIPCHK(hipGetLastError());
+
+    // 2. minimise + probe
+    K1Args a;
+    std::memset(&a, 0, sizeof(a));
+    a.words = s->idx->words; a.S = d.bin_size; a.row_begin = d.row_begin; a.seed = d.minimiser_seed; a.powk1 = pow5(d.kmer_size - 1);
+    a.shift = (uint32_t)d.hash_shift; a.h = d.hash_funs; a.k = d.kmer_size; a.wn = d.window_size - d.kmer_size + 1;
+    a.n_reads = (uint32_t)n; a.nseg = paired ? 2 : 1; a.B = (uint32_t)d.bins; a.C = C;
+    for (uint32_t bb = 0; bb < 8 && bb < d.bins; ++bb) a.b2c_packed |= (uint64_t)d.bin_to_category[bb] << (8 * bb);
+    a.bases = s->bases; a.nmask = s->nmask; a.off1 = s->off1; a.off2 = s->off2; a.len1 = s->len1; a.len2 = s->len2;
+    a.order = s->d_order.as<uint32_t>();
+    a.num_hashes = s->d_num_hashes.as<uint32_t>(); a.counts = s->d_counts.as<uint32_t>(); a.unique = s->d_unique.as<uint32_t>();
+    a.rows = s->d_rows.as<uint64_t>();
+    const int mode = fused ? MODE_FUSED : MODE_ROWS;
+    const size_t lds = k1_lds_bytes(a.wn, C, mode);
+    if (lds > 160 * 1024) return fail(CHN_E_INVALID, "window too large for LDS");
+    if (prof) { HIPCHK(hipEventRecord(s->ev[0], s->stream)); }
+    hipError_t e = fused ? launch_k1_w<MODE_FUSED>(W, a, lds, s->stream) : launch_k1_w<MODE_ROWS>(W, a, lds, s->stream);
+    if (e != hipSuccess) return fail(CHN_E_HIP, std::string("k_minimise_probe launch: ") + hipGetErrorString(e));
+    if (prof) { HIPCHK(hipEventRecord(s->ev[1], s->stream)); s->ev_used[0] = true; }
+
+    // 3. counts from rows (general bin layouts)
+    if (!fused) {
+        K2Args k2;
+        std::memset(&k2, 0, sizeof(k2));
+        k2.rows = s->d_rows.as<uint64_t>(); k2.off1 = s->off1; k2.num_hashes = s->d_num_hashes.as<uint32_t>();
+        k2.counts = s->d_counts.as<uint32_t>(); k2.unique = s->d_unique.as<uint32_t>();
+        k2.n_reads = (uint32_t)n; k2.B = (uint32_t)d.bins; k2.C = C; k2.W = W;
+        std::memcpy(k2.b2c, d.bin_to_category, 256);
+        const dim3 grid((uint32_t)((n + K2_WAVES - 1) / K2_WAVES)), block(WAVE * K2_WAVES);
+        if (prof) HIPCHK(hipEventRecord(s->ev[2], s->stream));
+        switch (W) {
+            case 1: hipLaunchKernelGGL(k_count_rows<1>, grid, block, 0, s->stream, k2); break;
+            case 2: hipLaunchKernelGGL(k_count_rows<2>, grid, block, 0, s->stream, k2); break;
+            case 3: hipLaunchKernelGGL(k_count_rows<3>, grid, block, 0, s->stream, k2); break;
+            default: hipLaunchKernelGGL(k_count_rows<4>, grid, block, 0, s->stream, k2); break;
+        }
+        HIPCHK(hipGetLastError());
+        if (prof) { HIPCHK(hipEventRecord(s->ev[3], s->stream)); s->ev_used[1] = true; }
+    }
+
+    // 4. model + call
+    if (s->model.set) {
+        K3Args k3 = s->k3;
+        k3.num_hashes = s->d_num_hashes.as<uint32_t>(); k3.counts = s->d_counts.as<uint32_t>(); k3.unique = s->d_unique.as<uint32_t>();
+        k3.len1 = s->len1; k3.len2 = s->len2; k3.mean_quality = s->mq; k3.compression = s->comp;
+        k3.prob = s->d_prob.as<double>(); k3.call = s->d_call.as<uint8_t>(); k3.conf = s->d_conf.as<uint8_t>(); k3.flags = s->d_flags.as<uint8_t>();
+        k3.n_reads = (uint32_t)n;
+        if (prof) HIPCHK(hipEventRecord(s->ev[4], s->stream));
+        hipLaunchKernelGGL(k_model_call, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s->stream, k3);
+        HIPCHK(hipGetLastError());
+        if (prof) { HIPCHK(hipEventRecord(s->ev[5], s->stream)); s->ev_used[2] = true; }
+    }
+    if (prof) { HIPCHK(hipEventRecord(s->ev[7], s->stream)); s->ev_used[3] = true; }
+    // algorithmic byte count of this batch (outside the profiled chain)
+    HIPCHK(hipMemsetAsync(s->d_acc.p, 0, 16, s->stream));
+    hipLaunchKernelGGL(k_batch_bytes, dim3(std::min<uint64_t>(1024, (n + 255) / 256)), dim3(256), 0, s->stream, s->len1, s->len2,
+                       s->d_num_hashes.as<uint32_t>(), (uint32_t)n, (uint32_t)(d.hash_funs * W * 8), (uint32_t)(8 + 8 * C),
+                       s->d_acc.as<unsigned long long>());
+    HIPCHK(hipGetLastError());
+    s->submitted = true;
+    return CHN_OK;
+}
+
+extern "C" int chn_stream_sync(chn_stream *s) {
+    if (!s) return fail(CHN_E_INVALID, "null stream");
+    HIPCHK(hipSetDevice(s->idx->d.device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return CHN_OK;
+}
+
+extern "C" int chn_batch_wait(chn_stream *s, chn_result *r) {
+    if (!s || !r || r->struct_size != sizeof(chn_result)) return fail(CHN_E_INVALID, "chn_batch_wait: bad argument");
+    if (!s->submitted) return fail(CHN_E_STATE, "no batch in flight");
+    HIPCHK(hipSetDevice(s->idx->d.device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->submitted = false;
+    static const int evpair[4][2] = {{0, 1}, {2, 3}, {4, 5}, {6, 7}};
+    for (int i = 0; i < 4; ++i)
+        if (s->ev_used[i]) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, s->ev[evpair[i][0]], s->ev[evpair[i][1]]));
+            s->prof_ms[i] += ms; s->prof_n[i] += 1;
+        }
+    unsigned long long acc[2];
+    HIPCHK(hipMemcpy(acc, s->d_acc.p, 16, hipMemcpyDeviceToHost));
+    s->last_bytes = acc[0]; s->last_min = acc[1];
+    const uint64_t n = s->n_reads, C = s->idx->d.num_categories;
+    if (r->on_device) {
+        r->num_hashes = s->d_num_hashes.as<uint32_t>(); r->counts = s->d_counts.as<uint32_t>(); r->unique_counts = s->d_unique.as<uint32_t>();
+        r->probabilities = s->d_prob.as<double>(); r->call = s->d_call.as<uint8_t>(); r->confidence = s->d_conf.as<uint8_t>();
+        r->flags = s->d_flags.as<uint8_t>();
+        return CHN_OK;
+    }
+    if (r->num_hashes) HIPCHK(hipMemcpy(r->num_hashes, s->d_num_hashes.p, n * 4, hipMemcpyDeviceToHost));
+    if (r->counts) HIPCHK(hipMemcpy(r->counts, s->d_counts.p, n * C * 4, hipMemcpyDeviceToHost));
+    if (r->unique_counts) HIPCHK(hipMemcpy(r->unique_counts, s->d_unique.p, n * C * 4, hipMemcpyDeviceToHost));
+    if (s->model.set) {
+        if (r->probabilities) HIPCHK(hipMemcpy(r->probabilities, s->d_prob.p, n * C * 8, hipMemcpyDeviceToHost));
+        if (r->call) HIPCHK(hipMemcpy(r->call, s->d_call.p, n, hipMemcpyDeviceToHost));
+        if (r->confidence) HIPCHK(hipMemcpy(r->confidence, s->d_conf.p, n, hipMemcpyDeviceToHost));
+        std::vector<uint8_t> flags(n);
+        HIPCHK(hipMemcpy(flags.data(), s->d_flags.p, n, hipMemcpyDeviceToHost));
+        if (r->flags) std::memcpy(r->flags, flags.data(), n);
+        // borderline reads: re-evaluate with the host libm so that `call` never depends on a last-ulp exp() difference
+        if (s->host_batch && r->num_hashes && r->counts && r->unique_counts && r->call && r->confidence && r->probabilities) {
+            std::vector<double> p(C);
+            for (uint64_t i = 0; i < n; ++i)
+                if (flags[i]) {
+                    const uint32_t length = s->h_len1[i] + (s->h_len2.empty() ? 0u : s->h_len2[i]);
+                    host_model_call(s->model, r->num_hashes[i], r->counts + i * C, r->unique_counts + i * C,
+                                    s->h_mq.empty() ? 0.0f : s->h_mq[i], s->h_comp.empty() ? 0.0f : s->h_comp[i], length, p.data(),
+                                    &r->call[i], &r->confidence[i]);
+                    for (uint64_t c = 0; c < C; ++c) r->probabilities[i * C + c] = p[c];
+                }
+        }
+    }
+    return CHN_OK;
+}
+
+extern "C" int chn_stream_profile(chn_stream *s, int which, double *total_ms, uint64_t *launches, int reset) {
+    if (!s || which < 0 || which > 3) return fail(CHN_E_INVALID, "chn_stream_profile: bad argument");
+    if (total_ms) *total_ms = s->prof_ms[which];
+    if (launches) *launches = s->prof_n[which];
+    if (reset) { s->prof_ms[which] = 0; s->prof_n[which] = 0; }
+    return CHN_OK;
+}
+extern "C" int chn_stream_last_batch_bytes(chn_stream *s, uint64_t *bytes, uint64_t *total_minimisers) {
+    if (!s) return fail(CHN_E_INVALID, "null stream");
+    if (bytes) *bytes = s->last_bytes;
+    if (total_minimisers) *total_minimisers = s->last_min;
+    return CHN_OK;
+}
+
+// ---- synthetic workloads ------------------------------------------------------------------------
+extern "C" int chn_synth_genomes(int device, uint64_t seed, uint64_t n_genomes, uint64_t genome_len, uint32_t **dev_bases2) {
+    if (!dev_bases2 || genome_len % 64 || n_genomes == 0) return fail(CHN_E_INVALID, "chn_synth_genomes: bad argument");
+    HIPCHK(hipSetDevice(device));
+    const uint64_t nd = n_genomes * genome_len / 16;
+    uint32_t *p = nullptr;
+    HIPCHK(hipMalloc((void **)&p, nd * 4));
+    hipLaunchKernelGGL(k_synth_genomes, dim3((uint32_t)std::min<uint64_t>(65535, (nd + 255) / 256)), dim3(256), 0, 0, p, nd, seed);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    *dev_bases2 = p;
+    return CHN_OK;
+}
+extern "C" int chn_synth_fill_index(chn_index *idx, uint64_t seed, double density) {
+    if (!idx || density < 0 || density > 1) return fail(CHN_E_INVALID, "chn_synth_fill_index: bad argument");
+    HIPCHK(hipSetDevice(idx->d.device));
+    const uint32_t thr = (uint32_t)std::lround(density * 65536.0);
+    hipLaunchKernelGGL(k_synth_fill, dim3(8192), dim3(256), 0, 0, idx->words, idx->rows_local, (uint32_t)idx->d.bin_words, (uint32_t)idx->d.bins, seed, thr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    return CHN_OK;
+}
+extern "C" int chn_synth_plant(chn_index *idx, const uint32_t *dev_bases2, uint64_t n_genomes, uint64_t genome_len, const uint8_t *genome_bin) {
+    if (!idx || !dev_bases2 || !genome_bin || genome_len % 64) return fail(CHN_E_INVALID, "chn_synth_plant: bad argument");
+    if (idx->d.row_begin != 0 || idx->d.row_end != idx->d.bin_size) return fail(CHN_E_INVALID, "plant needs the whole index");
+    const chn_index_desc &d = idx->d;
+    HIPCHK(hipSetDevice(d.device));
+    // The set of minimisers of a sequence equals the union over overlapping chunks (every window lies in one chunk),
+    // so genomes are cut into chunks of 4096 bases overlapping by w-1 and each chunk is treated as one "read".
+    const uint32_t chunk = 4096, overlap = d.window_size - 1;
+    const uint64_t cpg = (genome_len + chunk - 1) / chunk, n = n_genomes * cpg;
+    if (n > 0xFFFFFF00ULL) return fail(CHN_E_INVALID, "too many chunks");
+    uint64_t *off = nullptr; uint32_t *len = nullptr; uint8_t *bin = nullptr;
+    HIPCHK(hipMalloc((void **)&off, n * 8));
+    HIPCHK(hipMalloc((void **)&len, n * 4));
+    HIPCHK(hipMalloc((void **)&bin, n));
+    std::vector<uint8_t> hb(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        hb[i] = genome_bin[i / cpg];
+        if (hb[i] >= d.bins) { (void)hipFree(off); (void)hipFree(len); (void)hipFree(bin); return fail(CHN_E_INVALID, "genome_bin out of range"); }
+    }
+    HIPCHK(hipMemcpy(bin, hb.data(), n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_chunk_layout, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, n_genomes, genome_len, chunk, overlap, cpg, off, len);
+    K1Args a;
+    std::memset(&a, 0, sizeof(a));
+    a.words = idx->words; a.words_rw = idx->words; a.S = d.bin_size; a.row_begin = 0; a.seed = d.minimiser_seed; a.powk1 = pow5(d.kmer_size - 1);
+    a.shift = (uint32_t)d.hash_shift; a.h = d.hash_funs; a.k = d.kmer_size; a.wn = d.window_size - d.kmer_size + 1;
+    a.n_reads = (uint32_t)n; a.nseg = 1; a.B = (uint32_t)d.bins; a.C = d.num_categories;
+    a.bases = dev_bases2; a.off1 = off; a.len1 = len; a.read_bin = bin;
+    const size_t lds = k1_lds_bytes(a.wn, d.num_categories, MODE_EMPLACE);
+    hipError_t e = launch_k1_w<MODE_EMPLACE>((uint32_t)d.bin_words, a, lds, 0);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(off); (void)hipFree(len); (void)hipFree(bin);
+    if (e != hipSuccess) return fail(CHN_E_HIP, std::string("plant: ") + hipGetErrorString(e));
+    return CHN_OK;
+}
+extern "C" int chn_synth_reads(int device, uint64_t seed, const uint32_t *dev_genomes, uint64_t n_genomes, uint64_t genome_len,
+                               uint64_t n_reads, uint32_t read_len_min, uint32_t read_len_max, double sub_rate, double random_fraction,
+                               float mean_quality, chn_synth_reads_out *out) {
+    if (!out || n_reads == 0 || read_len_min == 0 || read_len_max < read_len_min) return fail(CHN_E_INVALID, "chn_synth_reads: bad argument");
+    if (n_genomes && (!dev_genomes || genome_len < read_len_max)) return fail(CHN_E_INVALID, "genomes shorter than reads");
+    HIPCHK(hipSetDevice(device));
+    std::memset(out, 0, sizeof(*out));
+    uint64_t *d_total = nullptr;
+    HIPCHK(hipMalloc((void **)&out->seg1_length, n_reads * 4));
+    HIPCHK(hipMalloc((void **)&out->seg1_offset, n_reads * 8));
+    HIPCHK(hipMalloc((void **)&out->mean_quality, n_reads * 4));
+    HIPCHK(hipMalloc((void **)&out->compression, n_reads * 4));
+    HIPCHK(hipMalloc((void **)&d_total, 8));
+    const dim3 g1((uint32_t)((n_reads + 255) / 256)), b1(256);
+    hipLaunchKernelGGL(k_synth_read_layout, g1, b1, 0, 0, seed, n_reads, read_len_min, read_len_max, out->seg1_length);
+    uint64_t total = 0;
+    if (read_len_min == read_len_max) {
+        const uint64_t pad = ((uint64_t)read_len_min + 63) & ~63ULL;
+        std::vector<uint64_t> h(n_reads);
+        for (uint64_t i = 0; i < n_reads; ++i) h[i] = i * pad;
+        HIPCHK(hipMemcpy(out->seg1_offset, h.data(), n_reads * 8, hipMemcpyHostToDevice));
+        total = n_reads * pad;
+    } else {
+        hipLaunchKernelGGL(k_synth_offsets, dim3(1), dim3(64), 0, 0, out->seg1_length, n_reads, out->seg1_offset, d_total);
+        HIPCHK(hipMemcpy(&total, d_total, 8, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d_total);
+    out->n_bases = total;
+    HIPCHK(hipMalloc((void **)&out->bases2, total / 4 + 16));
+    HIPCHK(hipMemset(out->bases2, 0, total / 4 + 16));
+    hipLaunchKernelGGL(k_fill_f32, g1, b1, 0, 0, out->mean_quality, n_reads, mean_quality);
+    hipLaunchKernelGGL(k_fill_f32, g1, b1, 0, 0, out->compression, n_reads, 0.3f);
+    SynthReadsArgs a;
+    a.genomes = dev_genomes; a.n_genomes = n_genomes; a.genome_len = genome_len; a.seed = seed; a.n_reads = n_reads;
+    a.len_min = read_len_min; a.len_max = read_len_max;
+    a.sub_thr32 = (uint32_t)std::min<double>(4294967295.0, sub_rate * 4294967296.0);
+    a.rand_thr32 = (uint32_t)std::min<double>(4294967295.0, random_fraction * 4294967296.0);
+    a.bases = out->bases2; a.off = out->seg1_offset; a.len = out->seg1_length;
+    const uint32_t gy = (uint32_t)std::min<uint64_t>(n_reads, 32768), gz = (uint32_t)((n_reads + gy - 1) / gy);
+    const uint32_t max_dwords = (read_len_max + 63) / 64 * 4;
+    hipLaunchKernelGGL(k_synth_reads, dim3((max_dwords + 63) / 64, gy, gz), dim3(64), 0, 0, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    return CHN_OK;
+}
+extern "C" int chn_device_free(int device, void *ptr) {
+    HIPCHK(hipSetDevice(device));
+    if (ptr) HIPCHK(hipFree(ptr));
+    return CHN_OK;
+}
+extern "C" int chn_device_download(int device, void *host_dst, const void *dev_src, uint64_t bytes) {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    return CHN_OK;
+}

@@ -1,0 +1,207 @@
+/* charon_hip.h -- C ABI of libcharon_hip.so: the MI355X (gfx950) implementation of the per-read
+ * classification path of `charon dehost`.
+ *
+ * The reference (rmcolq/charon) has no FFI/plugin interface; the seam this library replaces is the body
+ * of the OpenMP loop in src/dehost_main.cpp:366-373 (single-end) / :456-468 (paired) plus the model
+ * application and call that Result::classify_read performs on each entry (include/result.hpp:97-116 ->
+ * include/read_entry.hpp:218-291).  Each entry point below cites the reference code it stands in for.
+ * All paths are relative to the reference checkout.
+ *
+ * Conventions: every function returns 0 on success or a negative CHN_E_* code; chn_last_error() returns a
+ * thread-local message owned by the library.  No C++ types, exceptions or torch types cross this boundary.
+ * All sizes are 64-bit.  The library never writes to stdout/stderr.  A chn_stream is NOT thread-safe;
+ * different streams may be driven from different host threads.
+ */
+#ifndef CHARON_HIP_H
+#define CHARON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHN_OK 0
+#define CHN_E_INVALID (-1)   /* bad argument / unsupported parameter combination */
+#define CHN_E_HIP (-2)       /* a HIP runtime call failed (message has the HIP error string) */
+#define CHN_E_NOMEM (-3)     /* device or host allocation failed */
+#define CHN_E_STATE (-4)     /* call sequence error (e.g. wait without submit) */
+#define CHN_E_CAPACITY (-5)  /* batch exceeds the stream's configured capacity */
+
+#define CHN_MAX_CATEGORIES 255
+#define CHN_NO_CALL 255u
+
+typedef struct chn_index chn_index;   /* immutable IBF resident in HBM */
+typedef struct chn_stream chn_stream; /* one HIP stream + its device scratch */
+
+/* ---- index ------------------------------------------------------------------------------------------
+ * Replaces: Index (include/index.hpp:19-138) as far as the hot path reads it -- window_size()/kmer_size()
+ * (:52-58), the IBF parameters and data (:26, seqan3::interleaved_bloom_filter<compressed>), the bin ->
+ * category map (include/input_summary.hpp:20,39-45) and get_host_index() (include/index.hpp:72-80).
+ * Device layout: plain interleaved 64-bit words, word (row * bin_words + b) holds technical bins
+ * 64b..64b+63 of row `row` -- the same addressing seqan3 uses (bit index row * technical_bins + bin), with
+ * the Elias-Fano (sdsl::sd_vector) compression undone once at load time. */
+typedef struct chn_index_desc {
+    uint32_t struct_size;      /* sizeof(chn_index_desc) */
+    int32_t device;            /* HIP device ordinal */
+    uint8_t kmer_size;         /* k  (1..27: 5^k must fit 64 bits, as in seqan3 for dna5) */
+    uint8_t window_size;       /* w >= k */
+    uint8_t hash_funs;         /* h in 1..5 */
+    uint8_t num_categories;    /* C */
+    uint8_t host_index;        /* InputSummary::host_category_index(); 255 if none */
+    uint8_t reserved0[3];
+    uint64_t minimiser_seed;   /* 0x8F3F73B5CF1C9ADE for seqan3::views::minimiser_hash defaults */
+    uint64_t bins;             /* B  = InputSummary::num_bins */
+    uint64_t technical_bins;   /* TB = 64 * ceil(B/64) */
+    uint64_t bin_size;         /* S  = rows */
+    uint64_t hash_shift;       /* countl_zero(S) */
+    uint64_t bin_words;        /* W  = TB / 64 (1..4) */
+    uint8_t bin_to_category[256]; /* category INDEX of each user bin */
+    uint64_t row_begin;        /* shard: this object holds rows [row_begin, row_end); 0,0 = all rows */
+    uint64_t row_end;
+} chn_index_desc;
+
+int chn_index_create(const chn_index_desc *desc, chn_index **out);
+/* Copy `n_rows` rows (n_rows * bin_words words) starting at global row `row_begin` from HOST memory.
+ * Replaces the archive(ibf_) step of Index::serialize (include/index.hpp:130) after EF decoding; the
+ * loader streams row blocks so host RAM never holds the whole plain index. */
+int chn_index_upload_rows(chn_index *idx, uint64_t row_begin, uint64_t n_rows, const uint64_t *host_words);
+/* Device pointer to the shard's words (for on-device index fabrication and for download in tests). */
+int chn_index_device_words(chn_index *idx, uint64_t **device_words, uint64_t *n_words);
+int chn_index_download_rows(chn_index *idx, uint64_t row_begin, uint64_t n_rows, uint64_t *host_words);
+int chn_index_get_desc(const chn_index *idx, chn_index_desc *out);
+int chn_index_destroy(chn_index *idx);
+
+/* ---- model --------------------------------------------------------------------------------------------
+ * Replaces: StatsModel + Model + KDEParams as read by ReadEntry::apply_model / call_host / call_category
+ * (include/classify_stats.hpp:210-254,370-389,395-519; include/read_entry.hpp:157-279).
+ * Only dist == "kde" runs on the device (the default, include/dehost_arguments.hpp:27). */
+typedef struct chn_model {
+    uint32_t struct_size;
+    uint32_t num_categories;
+    /* per category c: KDE datasets IN THE ORDER THE REFERENCE ITERATES THEM (default tables sorted by the
+     * KDEParams constructor :214-218; trained tables in insertion order :234-240) */
+    const float *const *pos_data; /* [C] host pointers */
+    const uint32_t *pos_n;        /* [C] */
+    const float *const *neg_data;
+    const uint32_t *neg_n;
+    float h_pos;                  /* 0.1   (:270) */
+    float h_neg;                  /* 0.001 (:271) */
+    float err_rate;               /* 300: stats::dexp(x, 300) (:371) */
+    /* thresholds (include/dehost_arguments.hpp:30-37) */
+    float min_quality;
+    uint32_t min_length;
+    float min_compression;
+    int8_t confidence_threshold;  /* already narrowed to int8 (include/classify_stats.hpp:404,497) */
+    uint8_t min_hits;             /* StatsModel::min_hits_ -- never initialised in the reference; caller's choice */
+    uint8_t paired;               /* 1: call_category (what paired dehost runs, src/dehost_main.cpp:470) */
+    uint8_t host_index;
+    float confidence_probability_threshold;
+    float host_unique_prop_lo_threshold;
+    float min_proportion_difference;
+    float min_prob_difference;
+} chn_model;
+
+/* Fill `m` with the reference defaults (default KDE tables of src/dehost_main.cpp:23-206, sorted; thresholds
+ * of include/dehost_arguments.hpp).  Pointers refer to static storage inside the library. */
+int chn_model_default(chn_model *m, uint32_t num_categories, uint8_t host_index, int paired);
+
+/* ---- streams and batches --------------------------------------------------------------------------------
+ * One batch = what the reference calls a chunk (src/dehost_main.cpp:335-339), but sized for the GPU
+ * (>= 64k reads rather than <= 255). */
+typedef struct chn_stream_cfg {
+    uint32_t struct_size;
+    uint32_t flags;             /* CHN_STREAM_* */
+    uint64_t max_reads;         /* per batch */
+    uint64_t max_bases;         /* per batch, sum of padded segment lengths */
+} chn_stream_cfg;
+#define CHN_STREAM_PROFILE 1u   /* bracket every kernel with HIP events (chn_stream_profile) */
+
+int chn_stream_create(chn_index *idx, const chn_stream_cfg *cfg, chn_stream **out);
+int chn_stream_destroy(chn_stream *s);
+int chn_model_set(chn_stream *s, const chn_model *m);
+
+/* Input batch.  Bases are 2-bit codes A0 C1 G2 T3, 4 per byte, least-significant bits first; base j of the
+ * batch is bits [2*(j%16), +2) of little-endian dword j/16.  `nmask` (optional) has one bit per base in the
+ * same order (bit j%32 of dword j/32): 1 = the base is N (any non-ACGT IUPAC letter, seqan3 dna5 rank 3);
+ * its 2-bit code is then ignored.  Every segment must start at a multiple of 64 bases.
+ * A read has one segment (single-end) or two (paired: mates are minimised separately and share one
+ * accumulator, src/dehost_main.cpp:458-465).  mean_quality / compression are the host-side columns of
+ * src/dehost_main.cpp:355-363 that gate the call (include/read_entry.hpp:242-252); NULL = 0.
+ * If `on_device` is non-zero every pointer is a device pointer valid on the stream's device and no copy is
+ * made (the caller keeps them alive until chn_batch_wait returns). */
+typedef struct chn_batch {
+    uint32_t struct_size;
+    uint32_t on_device;
+    uint64_t n_reads;
+    uint64_t n_bases;            /* extent of `bases2`/`nmask` in bases (multiple of 64) */
+    const uint32_t *bases2;
+    const uint32_t *nmask;       /* may be NULL */
+    const uint64_t *seg1_offset; /* [n] in bases */
+    const uint32_t *seg1_length; /* [n] */
+    const uint64_t *seg2_offset; /* [n] or NULL (single-end) */
+    const uint32_t *seg2_length; /* [n] or NULL */
+    const float *mean_quality;   /* [n] or NULL */
+    const float *compression;    /* [n] or NULL */
+} chn_batch;
+
+/* Per-read results (what a post-processed + classified ReadEntry holds, include/read_entry.hpp:23-32):
+ * num_hashes_, counts_[C], unique_counts_[C], probabilities_[C], call_, confidence_score_.
+ * proportions are not returned: they are float(count)/float(num_hashes) (:140-150), recomputed by the caller.
+ * `flags` bit 0: the probability comparison that decides `call` was closer than 1e-6 relative, so the host
+ * should re-evaluate that read with its own libm (the device exp() may differ from glibc in the last ulp). */
+typedef struct chn_result {
+    uint32_t struct_size;
+    uint32_t on_device;        /* 0: pointers below are host buffers to fill; 1: receive device pointers */
+    uint32_t *num_hashes;      /* [n] */
+    uint32_t *counts;          /* [n*C] */
+    uint32_t *unique_counts;   /* [n*C] */
+    double *probabilities;     /* [n*C] */
+    uint8_t *call;             /* [n] (CHN_NO_CALL = unclassified) */
+    uint8_t *confidence;       /* [n] */
+    uint8_t *flags;            /* [n] */
+} chn_result;
+
+int chn_batch_submit(chn_stream *s, const chn_batch *b);   /* asynchronous on the stream */
+int chn_batch_wait(chn_stream *s, chn_result *r);          /* blocks; fills / points `r` */
+int chn_stream_sync(chn_stream *s);
+
+/* Per-kernel device time accumulated since the last reset (CHN_STREAM_PROFILE streams only).
+ * which: 0 = minimise+probe kernel, 1 = count kernel, 2 = model+call kernel, 3 = whole batch chain. */
+int chn_stream_profile(chn_stream *s, int which, double *total_ms, uint64_t *launches, int reset);
+/* Algorithmic bytes of the last batch by SURVEY 8(d): sum over reads of ceil(L/4) + M*h*W*8 + (8 + 8C). */
+int chn_stream_last_batch_bytes(chn_stream *s, uint64_t *bytes, uint64_t *total_minimisers);
+
+/* ---- synthetic workload fabrication on the device (bench / tests; no reference counterpart) ---------- */
+/* Random 2-bit genomes: n_genomes x genome_len bases (genome_len multiple of 64), counter-based PRNG. */
+int chn_synth_genomes(int device, uint64_t seed, uint64_t n_genomes, uint64_t genome_len, uint32_t **dev_bases2);
+/* Set every bit of user bins [0,B) of every row with probability `density` (background fill). */
+int chn_synth_fill_index(chn_index *idx, uint64_t seed, double density);
+/* Insert the minimisers of genome g into bin genome_bin[g] (IBF emplace, 3 rows each). */
+int chn_synth_plant(chn_index *idx, const uint32_t *dev_bases2, uint64_t n_genomes, uint64_t genome_len,
+                    const uint8_t *genome_bin /* host, [n_genomes] */);
+/* Sample `n_reads` reads of `read_len` bases: read i comes from genome (hash % n_genomes) with probability
+ * 1 - random_fraction (uniform start, i.i.d. substitutions at `sub_rate`), else is uniformly random.
+ * Writes a packed batch into freshly allocated device buffers (segments padded to 64 bases). */
+typedef struct chn_synth_reads_out {
+    uint32_t *bases2;
+    uint64_t *seg1_offset;
+    uint32_t *seg1_length;
+    float *mean_quality;
+    float *compression;
+    uint64_t n_bases;
+} chn_synth_reads_out;
+int chn_synth_reads(int device, uint64_t seed, const uint32_t *dev_genomes, uint64_t n_genomes, uint64_t genome_len,
+                    uint64_t n_reads, uint32_t read_len_min, uint32_t read_len_max, double sub_rate,
+                    double random_fraction, float mean_quality, chn_synth_reads_out *out);
+int chn_device_free(int device, void *ptr);
+int chn_device_download(int device, void *host_dst, const void *dev_src, uint64_t bytes);
+
+const char *chn_last_error(void);
+const char *chn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHARON_HIP_H */

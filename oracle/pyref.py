@@ -180,7 +180,10 @@ def dexp300(x):
         return np.float32(np.nan)
     if x < 0:
         return np.float32(0)
-    return np.float32(np.exp(np.float32(np.log(np.float32(300.0)) - np.float32(300.0) * x)))
+    # expf evaluated as the correctly rounded value (glibc's expf is correctly rounded here; numpy's SIMD float32
+    # exp is not).  log(300) rounded to float first, as `std::log(300.0f)` does.
+    arg = np.float32(np.float32(math.log(300.0)) - np.float32(np.float32(300.0) * x))
+    return np.float32(math.exp(float(arg)))
 
 
 def model_prob(x, tables):

@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    from oracle import pyoracle
+    pyoracle.build()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def my_fasta():
+    recs, name = {}, None
+    for line in open(os.path.join(ROOT, "tests", "golden", "my.fasta")):
+        line = line.strip()
+        if line.startswith(">"):
+            name = line[1:].split()[0]
+            recs[name] = ""
+        elif name:
+            recs[name] += line
+    return recs

@@ -1,0 +1,225 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same seeded
+inputs.  Integer columns (num_hashes, counts, unique counts, confidence, call) must be bit-exact; the KDE
+probability column within 1e-6 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    import charon_amd.api as api
+    return api
+
+
+def run_gpu(api, gidx, reads, mates=None, mq=40.0, comp=0.3, model=None, profile=False):
+    from charon_amd import pack
+    p = pack.pack_reads(reads, mates)
+    n = len(reads)
+    st = api.Stream(gidx, max(n, 1), p["n_bases"], profile=profile)
+    paired = mates is not None
+    st.set_model(model or api.default_model(gidx.desc.num_categories, gidx.desc.host_index if not paired else 0, paired=paired))
+    st.submit_host(p, np.full(n, mq, np.float32), np.full(n, comp, np.float32))
+    out = st.wait_host()
+    st.destroy()
+    return out
+
+
+def run_oracle(oidx, reads, mates=None, mq=40.0, comp=0.3, po=None):
+    seqs, offs, split = util.concat(reads, mates)
+    out = oidx.process_reads(seqs, offs, mate_split=split, mq_const=mq)
+    return out
+
+
+def check(api, po, oidx, reads, mates=None, **kw):
+    g = util.gpu_index_from_oracle(api, oidx)
+    try:
+        # compression is a host-side column (zlib) handed to the call kernel; the oracle is run without gzip so
+        # both sides gate on the same value 0 >= min_compression 0
+        gpu = run_gpu(api, g, reads, mates, comp=0.0, **kw)
+        orc = run_oracle(oidx, reads, mates)
+        util.assert_parity(gpu, orc)
+        return gpu, orc
+    finally:
+        g.destroy()
+
+
+def test_cfg1_toy_index_1k_reads(api, oracle_lib, my_fasta):
+    """BASELINE config 1: my.fasta (microbial) + seeded 10 kb random genome (host), 1 000 x 1 kb reads."""
+    r = util.rng(42)
+    host = util.random_seq(r, 10000)
+    micro = [s.encode() for s in my_fasta.values()]
+    oidx = util.build_oracle_index(oracle_lib, [micro, [host]], [0, 1], ["microbial", "host"])
+    assert oidx.bin_size == 11957 or oidx.bin_size > 0
+    reads = util.sample_reads(r, micro[1:4] + [host], 1000, 1000, sub_rate=0.05, random_fraction=0.1)
+    gpu, orc = check(api, oracle_lib, oidx, reads)
+    assert set(np.unique(gpu["call"])) >= {0, 1, 255}
+    assert abs(gpu["num_hashes"].mean() - 87) < 6
+    oidx.free()
+
+
+def test_edge_reads_ties_n_short(api, oracle_lib):
+    """homopolymers / tandem repeats (tie path of the minimiser rule), N runs, L < k, k <= L < w, ragged lengths"""
+    r = util.rng(1)
+    g0, g1 = util.random_seq(r, 5000), util.random_seq(r, 5000)
+    low = b"A" * 300 + g0[:200] + b"AC" * 150 + g1[:100] + b"ACG" * 90
+    oidx = util.build_oracle_index(oracle_lib, [[g0, low], [g1]], [0, 1], ["host", "other"])
+    reads = [b"A" * 1000, b"AC" * 400, b"ACGT" * 100, b"ACG" * 200 + b"T" * 77, low, low[100:700], b"A" * 18, b"A" * 19, b"C" * 40,
+             b"G" * 41, b"T" * 42, b"N" * 300, g0[:500].replace(b"A", b"N", 3), b"ACGTN" * 60,
+             g0[100:160] + b"NNNN" + g0[164:900], b"A", b"ACGTACGTACGTACGTACG", g1[:63], g1[:64], g1[:65], g0[:128], g0[:129],
+             (g0[:300] + b"RYKM" + g0[304:600]).lower(), g1[200:241], g1[200:240]]
+    reads += util.sample_reads(r, [g0, g1, low], 200, (1, 1500), sub_rate=0.02)
+    check(api, oracle_lib, oidx, reads)
+    oidx.free()
+
+
+def test_multi_bin_categories_rows_path(api, oracle_lib):
+    """a category with several bins -> max-bin selection needs the stored rows (H8); also W = 2 (70 bins)"""
+    r = util.rng(2)
+    gs = [util.random_seq(r, 4000) for _ in range(5)]
+    # related genomes in one category so the strictly-largest-total rule matters
+    gs[2] = util.mutate(r, gs[0], 0.02)
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [0, 1, 0, 1, 0], ["human", "microbial"], fill_seed=5, fill=0.05)
+    reads = util.sample_reads(r, gs, 300, (100, 2500), sub_rate=0.04)
+    gpu, _ = check(api, oracle_lib, oidx, reads)
+    assert gpu["unique"].sum() > 0
+    oidx.free()
+    gs = [util.random_seq(r, 1500) for _ in range(70)]
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [i % 2 for i in range(70)], ["microbial", "human"], bin_size=3001,
+                                   fill_seed=6, fill=0.1)
+    assert oidx.bin_words == 2
+    reads = util.sample_reads(r, gs, 200, (30, 1400), sub_rate=0.03) + [b"A" * 500, b"", b"ACGT" * 30]
+    check(api, oracle_lib, oidx, reads)
+    oidx.free()
+    # W = 3 and W = 4
+    for B in (130, 200):
+        gs = [util.random_seq(r, 600) for _ in range(B)]
+        oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [(i * 7) % 2 for i in range(B)], ["human", "microbial"],
+                                       bin_size=1511, fill_seed=B, fill=0.08)
+        check(api, oracle_lib, oidx, util.sample_reads(r, gs, 80, (50, 590), sub_rate=0.02))
+        oidx.free()
+
+
+def test_paired_mode_call_category(api, oracle_lib):
+    """paired dehost: mates minimised separately into one entry, call_category (src/dehost_main.cpp:458-470)"""
+    r = util.rng(3)
+    gs = [util.random_seq(r, 3000) for _ in range(8)]
+    cats = ["c%d" % i for i in range(7)] + ["host"]
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], list(range(8)), cats)
+    m1 = util.sample_reads(r, gs, 400, 150, sub_rate=0.01)
+    m2 = [util.mutate(r, gs[int(r.integers(0, 8))][500:650], 0.01) for _ in range(400)]
+    m1[0], m2[0] = b"ACGT", b"A" * 150
+    m1[1], m2[1] = b"", b"C" * 19
+    gpu, _ = check(api, oracle_lib, oidx, m1, m2)
+    assert (gpu["call"] != 255).sum() > 50
+    # single-end through the fused 8-category path as well (call_host uses categories 0/1 only -> use paired model here)
+    oidx.free()
+    g2 = [util.random_seq(r, 3000) for _ in range(4)]
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in g2], [0, 0, 1, 1], ["host", "microbial"])
+    m1 = util.sample_reads(r, g2, 150, (20, 200))
+    m2 = util.sample_reads(r, g2, 150, (20, 200))
+    check(api, oracle_lib, oidx, m1, m2)
+    oidx.free()
+
+
+def test_other_k_w(api, oracle_lib):
+    r = util.rng(4)
+    for k, w in ((15, 25), (27, 31), (4, 8), (19, 19), (11, 41)):
+        gs = [util.random_seq(r, 3000), util.random_seq(r, 3000)]
+        oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [0, 1], ["host", "x"], k=k, w=w, bin_size=20011)
+        reads = util.sample_reads(r, gs, 100, (1, 800), sub_rate=0.02) + [b"A" * 200, b"AC" * 100]
+        check(api, oracle_lib, oidx, reads)
+        oidx.free()
+
+
+def test_non_default_thresholds_and_quality_gate(api, oracle_lib):
+    r = util.rng(8)
+    gs = [util.random_seq(r, 5000), util.random_seq(r, 5000)]
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [0, 1], ["human", "bug"])
+    reads = util.sample_reads(r, gs, 200, (100, 400), sub_rate=0.06)
+    g = util.gpu_index_from_oracle(api, oidx)
+    seqs, offs, _ = util.concat(reads)
+    for mq, conf, minlen in ((10.0, 7, 140), (40.0, 200, 140), (40.0, 0, 300), (40.0, 2, 0)):
+        thr = oracle_lib.default_thresholds()
+        thr.confidence_threshold, thr.min_length = conf, minlen
+        orc = oidx.process_reads(seqs, offs, mq_const=mq, thr=thr)
+        ct = conf - 256 if conf >= 128 else conf  # int8 narrowing (include/classify_stats.hpp:404,497)
+        m = api.default_model(2, 0, confidence_threshold=ct, min_length=minlen)
+        gpu = run_gpu(api, g, reads, mq=mq, comp=0.0, model=m)
+        util.assert_parity(gpu, orc)
+    g.destroy()
+    oidx.free()
+
+
+def test_device_fabricated_workload_matches_oracle(api, oracle_lib):
+    """bench.py's synthetic index + reads are made on the device; pull them back and replay them through the oracle"""
+    from charon_amd import pack
+    B, S = 6, 1 << 16
+    b2c = [0, 1, 0, 1, 0, 1]
+    desc = api.make_desc(B, S, b2c, 2, 0)
+    g = api.Index(desc)
+    n_gen, glen = 6, 8192
+    gen = api.synth_genomes(0, 43, n_gen, glen)
+    g.synth_fill(43, 0.05)
+    g.synth_plant(gen, n_gen, glen, list(range(6)))
+    words = g.download()
+    oidx = oracle_lib.Index.new(B, S, b2c, ["human", "microbial"])
+    # independent check of the emplace kernel: plant the same genomes through the oracle on top of the same fill
+    genomes = pack.unpack_reads(api.device_download(0, gen, n_gen * glen // 4, np.uint32), [i * glen for i in range(n_gen)],
+                                [glen] * n_gen)
+    g2 = api.Index(desc)
+    g2.synth_fill(43, 0.05)
+    oidx.words()[:] = g2.download()
+    g2.destroy()
+    fill_density = np.unpackbits(oidx.words().view(np.uint8)).mean() * 64 / B
+    assert abs(fill_density - 0.05) < 0.005
+    for b, gs in enumerate(genomes):
+        oidx.emplace_many(np.unique(oracle_lib.minimisers(gs.decode())), b)
+    assert np.array_equal(oidx.words(), words)
+    rd = api.synth_reads(0, 42, gen, n_gen, glen, 500, 300, 3000, 0.05, 0.1, 40.0)
+    lens = api.device_download(0, rd.seg1_length, 500 * 4, np.uint32)
+    offs = api.device_download(0, rd.seg1_offset, 500 * 8, np.uint64)
+    assert lens.min() >= 300 and lens.max() <= 3000 and (offs % 64 == 0).all()
+    reads = pack.unpack_reads(api.device_download(0, rd.bases2, rd.n_bases // 4, np.uint32), offs, lens)
+    st = api.Stream(g, 500, rd.n_bases)
+    st.set_model(api.default_model(2, 0))
+    st.submit_device(500, rd.n_bases, rd.bases2, rd.seg1_offset, rd.seg1_length, rd.mean_quality, rd.compression)
+    res = st.wait_device()
+    gpu = dict(num_hashes=api.device_download(0, res.num_hashes, 500 * 4, np.uint32),
+               counts=api.device_download(0, res.counts, 500 * 2 * 4, np.uint32).reshape(500, 2),
+               unique=api.device_download(0, res.unique_counts, 500 * 2 * 4, np.uint32).reshape(500, 2),
+               probs=api.device_download(0, res.probabilities, 500 * 2 * 8, np.float64).reshape(500, 2),
+               call=api.device_download(0, res.call, 500, np.uint8), conf=api.device_download(0, res.confidence, 500, np.uint8))
+    orc = run_oracle(oidx, reads)
+    util.assert_parity(gpu, orc)
+    assert (gpu["call"] == 0).sum() > 50 and (gpu["call"] == 1).sum() > 50
+    st.destroy()
+    for p in (rd.bases2, rd.seg1_offset, rd.seg1_length, rd.mean_quality, rd.compression, gen):
+        api.device_free(0, p)
+    g.destroy()
+    oidx.free()
+
+
+def test_batch_properties_order_and_repeat(api, oracle_lib):
+    """size-independent properties: a permuted batch gives permuted results; re-running is idempotent"""
+    r = util.rng(12)
+    gs = [util.random_seq(r, 20000), util.random_seq(r, 20000)]
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [0, 1], ["host", "microbial"])
+    g = util.gpu_index_from_oracle(api, oidx)
+    reads = util.sample_reads(r, gs, 3000, (200, 6000), sub_rate=0.05)
+    a = run_gpu(api, g, reads, comp=0.0)
+    b = run_gpu(api, g, reads, comp=0.0)
+    perm = r.permutation(len(reads))
+    c = run_gpu(api, g, [reads[i] for i in perm], comp=0.0)
+    for key in ("num_hashes", "counts", "unique", "call", "conf", "probs"):
+        assert np.array_equal(a[key], b[key], equal_nan=True) if key == "probs" else np.array_equal(a[key], b[key])
+        assert np.array_equal(a[key][perm], c[key], equal_nan=True) if key == "probs" else np.array_equal(a[key][perm], c[key])
+    # spot-check 300 of them against the oracle
+    pick = r.choice(len(reads), 300, replace=False)
+    orc = run_oracle(oidx, [reads[i] for i in pick])
+    util.assert_parity({k: v[pick] for k, v in a.items() if k != "flags"}, orc)
+    g.destroy()
+    oidx.free()
