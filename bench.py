@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the `charon dehost` per-read classification hot path on MI355X.
+
+One "step" = one pass of the whole device chain (length ordering -> minimise+probe -> count -> KDE model+call)
+over one batch of synthetic reads that is already resident in HBM.  Workloads:
+
+  39g   (default) 5 kb reads vs the 39 GB stand-in index: B=100 bins (50 human / 50 microbial), TB=128, W=2,
+        S=2 437 500 000 rows, background fill 21.5 %, one planted genome per bin; reads 45/45/10 % host / microbial /
+        random with 5 % substitutions.  This is the configuration BASELINE.json's metric is quoted on.
+  cfg2  5 kb reads vs the 2-category 1 GiB index (B=2, W=1, S=2^27)  -- BASELINE configs[1]
+  small tiny smoke-sized variant of cfg2 (CPU-container rehearsal of the harness is impossible: needs a GPU)
+
+Multi-GPU (`--gpus N`, launched by torch.distributed.run): the 39 GB index fits every GPU, so the path shards by
+READ with a full index replica per rank and no data-path collective ("weak" scaling: per-GPU batch fixed).  The
+only collective is the barrier / max-reduce of the timing contract and one all-reduce of the summary counters.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+WORKLOADS = {
+    # name: bins, rows, genome_len per bin, description
+    "39g": dict(bins=100, rows=2437500000, genome_len=1 << 22, reads=1 << 20, read_len=5000, fill=0.215,
+                desc="5 kb synthetic reads vs 39 GB stand-in index (B=100, TB=128, W=2, S=2437500000, h=3, k=19, w=41)"),
+    "cfg2": dict(bins=2, rows=1 << 27, genome_len=1 << 24, reads=1 << 20, read_len=5000, fill=0.215,
+                 desc="5 kb synthetic reads vs 2-category 1 GiB index (B=2, TB=64, W=1, S=2^27, h=3, k=19, w=41)"),
+    "small": dict(bins=2, rows=1 << 20, genome_len=1 << 16, reads=1 << 14, read_len=1000, fill=0.1,
+                  desc="1 kb synthetic reads vs toy 2-category index (harness check)"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="39g", choices=sorted(WORKLOADS))
+    ap.add_argument("--reads-per-step", type=int, default=0, help="per GPU; default from the workload")
+    ap.add_argument("--read-len", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-reads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    import charon_amd.api as api
+    wl = dict(WORKLOADS[args.workload])
+    if args.reads_per_step:
+        wl["reads"] = args.reads_per_step
+    if args.read_len:
+        wl["read_len"] = args.read_len
+    B, S, n_reads, L = wl["bins"], wl["rows"], wl["reads"], wl["read_len"]
+    b2c = [b % 2 for b in range(B)]  # even bins: category 0 (human), odd bins: category 1 (microbial)
+    categories = ["human", "microbial"]
+
+    t_setup = time.time()
+    desc = api.make_desc(B, S, b2c, 2, 0, device=local)
+    index = api.Index(desc)
+    index.synth_fill(43, wl["fill"])
+    genomes = api.synth_genomes(local, 43, B, wl["genome_len"])
+    index.synth_plant(genomes, B, wl["genome_len"], list(range(B)))
+    reads = api.synth_reads(local, 42 + rank, genomes, B, wl["genome_len"], n_reads, L, L, 0.05, 0.10, 40.0)
+    stream = api.Stream(index, n_reads, reads.n_bases, profile=True)
+    stream.set_model(api.default_model(2, 0))
+    setup_s = time.time() - t_setup
+
+    def step():
+        stream.submit_device(n_reads, reads.n_bases, reads.bases2, reads.seg1_offset, reads.seg1_length, reads.mean_quality,
+                             reads.compression)
+        return stream.wait_device()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    for w in range(4):
+        stream.profile(w, reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    res = None
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # summary counters (ResultSummary, include/result.hpp:18-25): the one collective of the read-sharded mode
+    call = api.device_download(local, res.call, n_reads, np.uint8)
+    summary = np.array([(call == 0).sum(), (call == 1).sum(), (call == 255).sum()], dtype=np.int64)
+    if world > 1:
+        ts = torch.tensor(summary, device="cuda")
+        dist.all_reduce(ts)
+        summary = ts.cpu().numpy()
+
+    k1_ms, k1_n = stream.profile(0)
+    k2_ms, k2_n = stream.profile(1)
+    k3_ms, k3_n = stream.profile(2)
+    chain_ms, chain_n = stream.profile(3)
+    alg_bytes, total_min = stream.last_batch_bytes()
+    flags = api.device_download(local, res.flags, n_reads, np.uint8)
+
+    out = None
+    if rank == 0:
+        k1_avg = k1_ms / max(k1_n, 1)
+        achieved = alg_bytes / (k1_avg * 1e-3) / 1e9 if k1_avg > 0 else 0.0
+        out = {
+            "metric": "classified reads/sec + achieved HBM GB/s vs roofline, 5 kb reads, 39 GB index",
+            "value": world * args.steps * n_reads / elapsed,
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": wl["desc"], "reads_per_step_per_gpu": n_reads, "read_len": L, "index_bytes": S * ((B + 63) // 64) * 8,
+                       "sharding": "reads sharded over ranks, full index replica per GPU, no data-path collective",
+                       "mean_minimisers_per_read": total_min / n_reads, "borderline_reads": int(flags.sum()),
+                       "summary_counts": {"human": int(summary[0]), "microbial": int(summary[1]), "unclassified": int(summary[2])},
+                       "setup_seconds": round(setup_s, 1)},
+            "roofline": {"bound": "hbm", "kernel": "k_minimise_probe", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_avg,
+                         "other_kernels_avg_ms": {"k_count_rows": k2_ms / max(k2_n, 1), "k_model_call": k3_ms / max(k3_n, 1),
+                                                  "whole_chain": chain_ms / max(chain_n, 1)}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(api, index, reads, res, n_reads, args, local, categories, b2c)
+    stream.destroy()
+    index.destroy()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def cpu_baseline(api, index, reads, res, n_reads, args, device, categories, b2c):
+    """The CPU oracle (a port: restatement of the reference path with plain-word probes, no per-read gzip) timed on a
+    bounded sample of the same reads against the same index, on this box's host cores; also re-checks GPU parity on
+    that sample."""
+    from charon_amd import pack
+    from oracle import pyoracle as po
+    d = index.desc
+    oidx = po.Index.new(d.bins, d.bin_size, b2c, categories, k=d.kmer_size, w=d.window_size, nhash=d.hash_funs)
+    words = oidx.words()
+    chunk_rows = max(1, (1 << 30) // (8 * d.bin_words))
+    for r0 in range(0, d.bin_size, chunk_rows):
+        nr = min(chunk_rows, d.bin_size - r0)
+        rc = api.lib().chn_index_download_rows(index.h, r0, nr, words[r0 * d.bin_words:].ctypes.data)
+        if rc != 0:
+            raise RuntimeError("index download failed")
+    threads = min(os.cpu_count() or 1, 255)
+    sample = args.cpu_sample_reads or 4096
+    sample = min(sample, n_reads)
+    lens = api.device_download(device, reads.seg1_length, sample * 4, np.uint32)
+    offs = api.device_download(device, reads.seg1_offset, sample * 8, np.uint64)
+    nb = int(offs[-1] + ((int(lens[-1]) + 63) // 64) * 64)
+    seqs = pack.unpack_reads(api.device_download(device, reads.bases2, nb // 4, np.uint32), offs, lens)
+    cat, o = b"".join(seqs), np.concatenate([[0], np.cumsum(lens.astype(np.uint64))]).astype(np.uint64)
+    # calibrate on 256 reads, then size the timed sample to ~15 s
+    r = oidx.process_reads(cat[:int(o[256])] if sample > 256 else cat, o[:257] if sample > 256 else o, threads=threads)
+    rate = min(256, sample) / max(r["seconds"], 1e-6)
+    n_timed = int(min(sample, max(256, rate * 15)))
+    r = oidx.process_reads(cat[:int(o[n_timed])], o[:n_timed + 1], threads=threads)
+    gpu_call = api.device_download(device, res.call, n_reads, np.uint8)[:n_timed]
+    gpu_nh = api.device_download(device, res.num_hashes, n_reads * 4, np.uint32)[:n_timed]
+    gpu_cnt = api.device_download(device, res.counts, n_reads * 8, np.uint32).reshape(-1, 2)[:n_timed]
+    gpu_unq = api.device_download(device, res.unique_counts, n_reads * 8, np.uint32).reshape(-1, 2)[:n_timed]
+    parity = bool(np.array_equal(gpu_call, r["call"]) and np.array_equal(gpu_nh, r["num_hashes"]) and
+                  np.array_equal(gpu_cnt, r["counts"]) and np.array_equal(gpu_unq, r["unique"]))
+    oidx.free()
+    return {"value": n_timed / r["seconds"], "unit": "reads/s", "cores": threads, "kind": "port",
+            "sample": "%d of the same 5 kb reads vs the same index (downloaded from HBM), oracle hot path only: minimisers + "
+                      "plain-word IBF probes + counts + KDE + call, OpenMP over reads, no per-read gzip column" % n_timed,
+            "gpu_parity_on_sample": parity}
+
+
+if __name__ == "__main__":
+    main()
