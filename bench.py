@@ -181,7 +181,8 @@ def cpu_baseline(api, index, reads, res, n_reads, args, device, categories, b2c)
         rc = api.lib().chn_index_download_rows(index.h, r0, nr, words[r0 * d.bin_words:].ctypes.data)
         if rc != 0:
             raise RuntimeError("index download failed")
-    threads = min(os.cpu_count() or 1, 255)
+    # the reference's -t is a uint8 (<= 255); a 1-GPU box gives this job a 16-CPU share, so use the affinity mask, capped
+    threads = max(1, min(len(os.sched_getaffinity(0)), 64))
     sample = args.cpu_sample_reads or 4096
     sample = min(sample, n_reads)
     lens = api.device_download(device, reads.seg1_length, sample * 4, np.uint32)

@@ -127,15 +127,22 @@ __device__ __forceinline__ void load_row_and(const uint64_t *p, uint64_t *acc) {
     }
 }
 
-template <int W, int MODE>
+// Sliding-window minimum without rescans.  Value indices are cut into blocks of wn; slot u of the per-lane LDS
+// ring holds, for u <= t (t = offset of the newest value in its block), the raw values of the current block and,
+// for u > t, the rightmost suffix minimum S[u] of the PREVIOUS block (value in `ring`, offset in `spos`).  The
+// rightmost minimum of the window ending at offset t is then combine(S[t+1], running prefix minimum), and the
+// suffix minima are produced in place by one backward pass at every block end (all lanes are at the same t).
+template <int W, int MODE, int WN_T>
 __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
     extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t wn = WN_T ? (uint32_t)WN_T : a.wn;
     // LDS carve-up (one wavefront per workgroup)
-    uint64_t *ring = reinterpret_cast<uint64_t *>(smem);                      // [wn][64] window values per lane
-    uint64_t *qv = ring + (size_t)a.wn * WAVE;                                // [QCAP] queued minimiser values
+    uint64_t *ring = reinterpret_cast<uint64_t *>(smem);                      // [wn][64] per-lane window store
+    uint64_t *qv = ring + (size_t)wn * WAVE;                                  // [QCAP] queued minimiser values
     uint32_t *qm = reinterpret_cast<uint32_t *>(qv + QCAP);                   // [QCAP] owner lane | idx << 6
     uint64_t *rbase = reinterpret_cast<uint64_t *>(qm + QCAP);                // [64] MODE_ROWS row base / EMPLACE bin
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(rbase + WAVE);               // MODE_FUSED [C][64]
+    uint32_t *spos = reinterpret_cast<uint32_t *>(rbase + WAVE);              // [wn][64] offset of S[u] in its block
+    uint32_t *cnt = spos + (size_t)wn * WAVE;                                 // MODE_FUSED [C][64]
     uint32_t *unq = cnt + (MODE == MODE_FUSED ? a.C * WAVE : 0);              // MODE_FUSED [C][64]
 
     const uint32_t lane = lane_id();
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
     if (MODE == MODE_EMPLACE) rbase[lane] = valid ? a.read_bin[r] : 0;
     __syncthreads();
 
-    const uint32_t k = a.k, wn = a.wn;
+    const uint32_t k = a.k;
     const uint64_t INV5 = 0xCCCCCCCCCCCCCCCDULL;  // 5^-1 mod 2^64 (exact division of the reverse strand)
     uint32_t my_emitted = 0;                      // == ReadEntry::num_hashes_ (include/read_entry.hpp:89)
     uint32_t qhead = 0, qcount = 0;               // wave-uniform queue state
@@ -211,14 +218,16 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
         const uint32_t maxL = wave_max_u32(L);
         const uint32_t *bp = a.bases + (off >> 4);
         const uint32_t *np = a.nmask ? a.nmask + (off >> 5) : nullptr;
-        uint64_t fwd = 0, rc = 0, hist2 = 0, mv = 0;
-        uint32_t histn = 0, cur = 0, ncur = 0, slot = 0, q = 0;
+        uint64_t fwd = 0, rc = 0, hist2 = 0, mv = 0, pv = 0;
+        uint32_t histn = 0, cur = 0, ncur = 0, q = 0, pq = 0;
+        uint32_t t = 0, blk = 0;  // wave-uniform: offset of the newest value in its block, start index of that block
 
         for (uint32_t i = 0; i < maxL; ++i) {
             const bool act = i < L;
             if ((i & 15u) == 0 && act) cur = bp[i >> 4];
             if (np && (i & 31u) == 0 && act) ncur = np[i >> 5];
             bool emit = false;
+            const bool have_value = i + 1 >= k;  // wave-uniform
             if (act) {
                 const uint32_t code = (cur >> ((i & 15u) * 2)) & 3u;
                 const uint32_t nf = np ? ((ncur >> (i & 31u)) & 1u) : 0u;
@@ -236,30 +245,46 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
                 histn = (histn << 1) | nf;
                 fwd = (fwd - (uint64_t)d_out * a.powk1) * 5u + d_in;
                 rc = (rc - cd_out) * INV5 + (uint64_t)cd_in * a.powk1;
-                if (i + 1 >= k) {
-                    const uint32_t p = i + 1 - k;  // index of this canonical value
+                if (have_value) {
+                    const uint32_t p = i + 1 - k;  // index of this canonical value (== blk + t)
                     const uint64_t vf = fwd ^ a.seed, vr = rc ^ a.seed;
                     const uint64_t v = vf < vr ? vf : vr;
-                    ring[slot * WAVE + lane] = v;
-                    if (p < wn) {  // first window still filling: track the rightmost minimum
-                        if (p == 0 || v <= mv) { mv = v; q = p; }
+                    // running rightmost minimum of the current block's prefix [blk, p]
+                    if (t == 0 || v <= pv) { pv = v; pq = p; }
+                    if (p < wn) {  // first window: its rightmost minimum is the prefix minimum of block 0
+                        mv = pv; q = pq;
                         emit = (p == wn - 1);
-                    } else if (q + wn == p) {  // tracked minimum left the window: rightmost minimum of the new one
-                        uint32_t sl = slot + 1 == wn ? 0 : slot + 1;  // oldest value of the new window
-                        uint64_t best = ring[sl * WAVE + lane];
-                        uint32_t bq = p + 1 - wn;
-                        for (uint32_t t = 1; t < wn; ++t) {
-                            sl = sl + 1 == wn ? 0 : sl + 1;
-                            const uint64_t x = ring[sl * WAVE + lane];
-                            if (x <= best) { best = x; bq = p + 1 - wn + t; }
+                    } else if (q + wn == p) {  // tracked minimum left the window: rightmost minimum of the new window
+                        mv = pv; q = pq;
+                        if (t + 1 < wn) {
+                            const uint64_t sv = ring[(t + 1) * WAVE + lane];
+                            if (sv < pv) { mv = sv; q = blk - wn + spos[(t + 1) * WAVE + lane]; }
                         }
-                        mv = best; q = bq; emit = true;
+                        emit = true;
                     } else if (v < mv) {
                         mv = v; q = p; emit = true;
                     }
-                    slot = slot + 1 == wn ? 0 : slot + 1;
+                    ring[t * WAVE + lane] = v;
                     // sequence shorter than one window: a single minimiser over all its values
                     if (i + 1 == L && p + 1 < wn) emit = true;
+                }
+            }
+            if (have_value) {
+                if (t + 1 == wn) {
+                    // block end: turn the raw values of this block into rightmost suffix minima, in place
+                    uint64_t sv = ring[(wn - 1) * WAVE + lane];
+                    uint32_t sp = wn - 1;
+                    spos[(wn - 1) * WAVE + lane] = sp;
+#pragma unroll
+                    for (int u = (int)wn - 2; u >= 1; --u) {
+                        const uint64_t x = ring[u * WAVE + lane];
+                        if (x < sv) { sv = x; sp = (uint32_t)u; }
+                        ring[u * WAVE + lane] = sv;
+                        spos[u * WAVE + lane] = sp;
+                    }
+                    t = 0; blk += wn;
+                } else {
+                    ++t;
                 }
             }
             const uint64_t mask = __ballot(emit);
@@ -506,8 +531,18 @@ __global__ void k_len_scan(uint32_t *hist /* in: counts, out: start cursor, long
     }
 }
 __global__ void k_len_scatter(const uint32_t *len1, const uint32_t *len2, uint32_t n, uint32_t *cursor, uint32_t *order) {
+    // block-aggregated: one global atomic per (block, bucket) instead of one per read (uniform-length batches put
+    // every read in the same bucket)
+    __shared__ uint32_t s_cnt[256], s_base[256];
+    s_cnt[threadIdx.x] = 0;
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) order[atomicAdd(&cursor[len_bucket(len1[i] + (len2 ? len2[i] : 0u))], 1u)] = i;
+    uint32_t b = 0, local = 0;
+    if (i < n) { b = len_bucket(len1[i] + (len2 ? len2[i] : 0u)); local = atomicAdd(&s_cnt[b], 1u); }
+    __syncthreads();
+    if (s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (i < n) order[s_base[b] + local] = i;
 }
 
 // algorithmic bytes of a batch: sum ceil(L/4) + M*h*W*8 + (8 + 8C)
@@ -926,7 +961,10 @@ extern "C" int chn_model_set(chn_stream *s, const chn_model *m) {
 template <int W, int MODE>
 static hipError_t launch_k1(const K1Args &a, size_t lds, hipStream_t st) {
     const uint32_t blocks = (a.n_reads + WAVE - 1) / WAVE;
-    hipLaunchKernelGGL((k_minimise_probe<W, MODE>), dim3(blocks), dim3(WAVE), lds, st, a);
+    if (a.wn == 23)  // w=41, k=19: the defaults every real Charon index uses (include/index_arguments.hpp:16-17)
+        hipLaunchKernelGGL((k_minimise_probe<W, MODE, 23>), dim3(blocks), dim3(WAVE), lds, st, a);
+    else
+        hipLaunchKernelGGL((k_minimise_probe<W, MODE, 0>), dim3(blocks), dim3(WAVE), lds, st, a);
     return hipGetLastError();
 }
 template <int MODE>
@@ -939,7 +977,7 @@ static hipError_t launch_k1_w(uint32_t W, const K1Args &a, size_t lds, hipStream
     }
 }
 static size_t k1_lds_bytes(uint32_t wn, uint32_t C, int mode) {
-    size_t b = (size_t)wn * WAVE * 8 + QCAP * 8 + QCAP * 4 + WAVE * 8;
+    size_t b = (size_t)wn * WAVE * 8 + QCAP * 8 + QCAP * 4 + WAVE * 8 + (size_t)wn * WAVE * 4;
     if (mode == MODE_FUSED) b += (size_t)2 * C * WAVE * 4;
     return b;
 }
