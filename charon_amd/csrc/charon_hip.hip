@@ -132,6 +132,11 @@ __device__ __forceinline__ void load_row_and(const uint64_t *p, uint64_t *acc) {
 // for u > t, the rightmost suffix minimum S[u] of the PREVIOUS block (value in `ring`, offset in `spos`).  The
 // rightmost minimum of the window ending at offset t is then combine(S[t+1], running prefix minimum), and the
 // suffix minima are produced in place by one backward pass at every block end (all lanes are at the same t).
+//
+// Probe rounds are software-pipelined: a round's h*W-word gathers are issued into registers and only consumed
+// (AND + accumulate / row store) when the next round is due ~11 bases later, so the HBM latency of the random
+// gathers overlaps the hash rolling of the same wavefront.  Bases are fetched 64 at a time (one dwordx4 per lane)
+// one chunk ahead, so the only vector-memory wait inside the base loop sits at a chunk boundary.
 template <int W, int MODE, int WN_T>
 __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -141,9 +146,9 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
     uint64_t *qv = ring + (size_t)wn * WAVE;                                  // [QCAP] queued minimiser values
     uint32_t *qm = reinterpret_cast<uint32_t *>(qv + QCAP);                   // [QCAP] owner lane | idx << 6
     uint64_t *rbase = reinterpret_cast<uint64_t *>(qm + QCAP);                // [64] MODE_ROWS row base / EMPLACE bin
-    uint32_t *spos = reinterpret_cast<uint32_t *>(rbase + WAVE);              // [wn][64] offset of S[u] in its block
-    uint32_t *cnt = spos + (size_t)wn * WAVE;                                 // MODE_FUSED [C][64]
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(rbase + WAVE);               // MODE_FUSED [C][64]
     uint32_t *unq = cnt + (MODE == MODE_FUSED ? a.C * WAVE : 0);              // MODE_FUSED [C][64]
+    uint8_t *spos = reinterpret_cast<uint8_t *>(unq + (MODE == MODE_FUSED ? a.C * WAVE : 0));  // [wn][64] offset of S[u]
 
     const uint32_t lane = lane_id();
     const uint32_t g = blockIdx.x * WAVE + lane;
@@ -160,26 +165,67 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
     const uint64_t INV5 = 0xCCCCCCCCCCCCCCCDULL;  // 5^-1 mod 2^64 (exact division of the reverse strand)
     uint32_t my_emitted = 0;                      // == ReadEntry::num_hashes_ (include/read_entry.hpp:89)
     uint32_t qhead = 0, qcount = 0;               // wave-uniform queue state
+    // in-flight probe round
+    uint64_t pend[5][W];
+    uint32_t pend_meta = 0;
+    bool pend_has = false;   // per lane
+    bool pending = false;    // wave-uniform
 
-    auto probe_round = [&](uint32_t n_take) {
+    auto probe_consume = [&]() {
+        if (MODE == MODE_EMPLACE) { pending = false; return; }
+        uint64_t acc[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) acc[w] = ~0ULL;
+        if (pend_has) {
+#pragma unroll
+            for (uint32_t i = 0; i < 5; ++i)
+                if (i < a.h) {
+#pragma unroll
+                    for (int w = 0; w < W; ++w) acc[w] &= pend[i][w];
+                }
+        }
+        const uint32_t owner = pend_meta & 63u, idx = pend_meta >> 6;
+        if (MODE == MODE_FUSED) {
+            uint64_t m = pend_has ? (acc[0] & ((a.B >= 64) ? ~0ULL : ((1ULL << a.B) - 1))) : 0;
+            const bool single = __popcll(m) == 1;
+            while (m) {
+                const uint32_t b = (uint32_t)__ffsll((long long)m) - 1;
+                m &= m - 1;
+                const uint32_t c = (uint32_t)(a.b2c_packed >> (8 * b)) & 0xffu;
+                atomicAdd(&cnt[c * WAVE + owner], 1u);
+                if (single) atomicAdd(&unq[c * WAVE + owner], 1u);
+            }
+        } else {  // MODE_ROWS: append to the owner's row list (order inside a read is irrelevant to the counts)
+            if (pend_has) {
+                uint64_t *dst = a.rows + (rbase[owner] + idx) * W;
+                if (W == 2) {
+                    *reinterpret_cast<ulonglong2 *>(dst) = make_ulonglong2(acc[0], acc[1]);
+                } else {
+#pragma unroll
+                    for (int w = 0; w < W; ++w) dst[w] = acc[w];
+                }
+            }
+        }
+        pending = false;
+    };
+
+    auto probe_issue = [&](uint32_t n_take) {
         __syncthreads();
         const bool has = lane < n_take;
         const uint32_t slot = (qhead + lane) & (QCAP - 1);
         const uint64_t val = qv[slot];
         const uint32_t meta = qm[slot];
-        const uint32_t owner = meta & 63u, idx = meta >> 6;
         if (MODE == MODE_EMPLACE) {
             if (has) {
-                const uint32_t bin = (uint32_t)rbase[owner];
+                const uint32_t bin = (uint32_t)rbase[meta & 63u];
                 for (uint32_t i = 0; i < a.h; ++i) {
                     uint64_t row = hash_and_fit_row(val, c_ibf_seeds[i], a.S, a.shift);
                     atomicOr((unsigned long long *)&a.words_rw[(row - a.row_begin) * W + (bin >> 6)], 1ULL << (bin & 63));
                 }
             }
         } else {
-            uint64_t acc[W];
-#pragma unroll
-            for (int w = 0; w < W; ++w) acc[w] = ~0ULL;
+            pend_has = has;
+            pend_meta = meta;
             if (has) {
                 uint64_t rows_[5];
 #pragma unroll
@@ -187,25 +233,23 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
                     if (i < a.h) rows_[i] = hash_and_fit_row(val, c_ibf_seeds[i], a.S, a.shift);
 #pragma unroll
                 for (uint32_t i = 0; i < 5; ++i)
-                    if (i < a.h) load_row_and<W>(a.words + (rows_[i] - a.row_begin) * W, acc);
+                    if (i < a.h) {
+                        const uint64_t *p = a.words + (rows_[i] - a.row_begin) * W;
+                        if (W == 1) {
+                            pend[i][0] = p[0];
+                        } else if (W == 2) {
+                            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p);
+                            pend[i][0] = v.x; pend[i][W > 1 ? 1 : 0] = v.y;
+                        } else if (W == 3) {
+                            pend[i][0] = p[0]; pend[i][W > 1 ? 1 : 0] = p[1]; pend[i][W > 2 ? 2 : 0] = p[2];
+                        } else {
+                            const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(p);
+                            const ulonglong2 v1 = *reinterpret_cast<const ulonglong2 *>(p + 2);
+                            pend[i][0] = v0.x; pend[i][W > 1 ? 1 : 0] = v0.y; pend[i][W > 2 ? 2 : 0] = v1.x; pend[i][W > 3 ? 3 : 0] = v1.y;
+                        }
+                    }
             }
-            if (MODE == MODE_FUSED) {
-                uint64_t m = has ? (acc[0] & ((a.B >= 64) ? ~0ULL : ((1ULL << a.B) - 1))) : 0;
-                const bool single = __popcll(m) == 1;
-                while (m) {
-                    const uint32_t b = (uint32_t)__ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const uint32_t c = (uint32_t)(a.b2c_packed >> (8 * b)) & 0xffu;
-                    atomicAdd(&cnt[c * WAVE + owner], 1u);
-                    if (single) atomicAdd(&unq[c * WAVE + owner], 1u);
-                }
-            } else {  // MODE_ROWS: append to the owner's row list (order inside a read is irrelevant to the counts)
-                if (has) {
-                    uint64_t *dst = a.rows + (rbase[owner] + idx) * W;
-#pragma unroll
-                    for (int w = 0; w < W; ++w) dst[w] = acc[w];
-                }
-            }
+            pending = true;
         }
         qhead = (qhead + n_take) & (QCAP - 1);
         qcount -= n_take;
@@ -216,100 +260,121 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
         const uint32_t L = valid ? (s == 0 ? a.len1[r] : a.len2[r]) : 0;
         const uint64_t off = valid ? (s == 0 ? a.off1[r] : a.off2[r]) : 0;
         const uint32_t maxL = wave_max_u32(L);
-        const uint32_t *bp = a.bases + (off >> 4);
-        const uint32_t *np = a.nmask ? a.nmask + (off >> 5) : nullptr;
+        const uint4 *bp = reinterpret_cast<const uint4 *>(a.bases + (off >> 4));   // 64 bases per uint4
+        const uint2 *np = a.nmask ? reinterpret_cast<const uint2 *>(a.nmask + (off >> 5)) : nullptr;
         uint64_t fwd = 0, rc = 0, hist2 = 0, mv = 0, pv = 0;
-        uint32_t histn = 0, cur = 0, ncur = 0, q = 0, pq = 0;
+        uint32_t histn = 0, q = 0, pq = 0;
         uint32_t t = 0, blk = 0;  // wave-uniform: offset of the newest value in its block, start index of that block
 
-        for (uint32_t i = 0; i < maxL; ++i) {
-            const bool act = i < L;
-            if ((i & 15u) == 0 && act) cur = bp[i >> 4];
-            if (np && (i & 31u) == 0 && act) ncur = np[i >> 5];
-            bool emit = false;
-            const bool have_value = i + 1 >= k;  // wave-uniform
-            if (act) {
-                const uint32_t code = (cur >> ((i & 15u) * 2)) & 3u;
-                const uint32_t nf = np ? ((ncur >> (i & 31u)) & 1u) : 0u;
-                // dna5 ranks A0 C1 G2 N3 T4; complement table [4,2,1,3,0]
-                const uint32_t d_in = nf ? 3u : code + (code == 3u);
-                const uint32_t cd_in = nf ? 3u : (3u - code) + (code == 0u);
-                uint32_t d_out = 0, cd_out = 0;
-                if (i >= k) {
-                    const uint32_t oc = (uint32_t)(hist2 >> (2 * (k - 1))) & 3u;
-                    const uint32_t on = (histn >> (k - 1)) & 1u;
-                    d_out = on ? 3u : oc + (oc == 3u);
-                    cd_out = on ? 3u : (3u - oc) + (oc == 0u);
-                }
-                hist2 = (hist2 << 2) | code;
-                histn = (histn << 1) | nf;
-                fwd = (fwd - (uint64_t)d_out * a.powk1) * 5u + d_in;
-                rc = (rc - cd_out) * INV5 + (uint64_t)cd_in * a.powk1;
-                if (have_value) {
-                    const uint32_t p = i + 1 - k;  // index of this canonical value (== blk + t)
-                    const uint64_t vf = fwd ^ a.seed, vr = rc ^ a.seed;
-                    const uint64_t v = vf < vr ? vf : vr;
-                    // running rightmost minimum of the current block's prefix [blk, p]
-                    if (t == 0 || v <= pv) { pv = v; pq = p; }
-                    if (p < wn) {  // first window: its rightmost minimum is the prefix minimum of block 0
-                        mv = pv; q = pq;
-                        emit = (p == wn - 1);
-                    } else if (q + wn == p) {  // tracked minimum left the window: rightmost minimum of the new window
-                        mv = pv; q = pq;
-                        if (t + 1 < wn) {
-                            const uint64_t sv = ring[(t + 1) * WAVE + lane];
-                            if (sv < pv) { mv = sv; q = blk - wn + spos[(t + 1) * WAVE + lane]; }
+        const uint32_t nchunk = (maxL + 63) >> 6;
+        uint4 wnext = make_uint4(0, 0, 0, 0);
+        uint2 nnext = make_uint2(0, 0);
+        if (L > 0) { wnext = bp[0]; if (np) nnext = np[0]; }
+        for (uint32_t c = 0; c < nchunk; ++c) {
+            const uint4 wcur = wnext;
+            const uint2 ncur2 = nnext;
+            if ((c + 1) * 64 < L) { wnext = bp[c + 1]; if (np) nnext = np[c + 1]; }
+            for (uint32_t dd = 0; dd < 4; ++dd) {
+                const uint32_t cur = dd == 0 ? wcur.x : dd == 1 ? wcur.y : dd == 2 ? wcur.z : wcur.w;
+                const uint32_t ncur = dd < 2 ? ncur2.x : ncur2.y;
+                const uint32_t ibase = c * 64 + dd * 16;
+                if (ibase >= maxL) break;
+                const uint32_t jn = maxL - ibase < 16 ? maxL - ibase : 16;
+                for (uint32_t j = 0; j < jn; ++j) {
+                    const uint32_t i = ibase + j;
+                    const bool act = i < L;
+                    bool emit = false;
+                    const bool have_value = i + 1 >= k;  // wave-uniform
+                    if (act) {
+                        const uint32_t code = (cur >> (j * 2)) & 3u;
+                        const uint32_t nf = np ? ((ncur >> (i & 31u)) & 1u) : 0u;
+                        // dna5 ranks A0 C1 G2 N3 T4; complement table [4,2,1,3,0]
+                        const uint32_t d_in = nf ? 3u : code + (code == 3u);
+                        const uint32_t cd_in = nf ? 3u : (3u - code) + (code == 0u);
+                        uint32_t d_out = 0, cd_out = 0;
+                        if (i >= k) {
+                            const uint32_t oc = (uint32_t)(hist2 >> (2 * (k - 1))) & 3u;
+                            const uint32_t on = (histn >> (k - 1)) & 1u;
+                            d_out = on ? 3u : oc + (oc == 3u);
+                            cd_out = on ? 3u : (3u - oc) + (oc == 0u);
                         }
-                        emit = true;
-                    } else if (v < mv) {
-                        mv = v; q = p; emit = true;
+                        hist2 = (hist2 << 2) | code;
+                        histn = (histn << 1) | nf;
+                        fwd = (fwd - (uint64_t)d_out * a.powk1) * 5u + d_in;
+                        rc = (rc - cd_out) * INV5 + (uint64_t)cd_in * a.powk1;
+                        if (have_value) {
+                            const uint32_t p = i + 1 - k;  // index of this canonical value (== blk + t)
+                            const uint64_t vf = fwd ^ a.seed, vr = rc ^ a.seed;
+                            const uint64_t v = vf < vr ? vf : vr;
+                            // running rightmost minimum of the current block's prefix [blk, p]
+                            if (t == 0 || v <= pv) { pv = v; pq = p; }
+                            if (p < wn) {  // first window: its rightmost minimum is the prefix minimum of block 0
+                                mv = pv; q = pq;
+                                emit = (p == wn - 1);
+                            } else if (q + wn == p) {  // tracked minimum left the window: rightmost minimum of the new one
+                                mv = pv; q = pq;
+                                if (t + 1 < wn) {
+                                    const uint64_t sv = ring[(t + 1) * WAVE + lane];
+                                    if (sv < pv) { mv = sv; q = blk - wn + spos[(t + 1) * WAVE + lane]; }
+                                }
+                                emit = true;
+                            } else if (v < mv) {
+                                mv = v; q = p; emit = true;
+                            }
+                            ring[t * WAVE + lane] = v;
+                            // sequence shorter than one window: a single minimiser over all its values
+                            if (i + 1 == L && p + 1 < wn) emit = true;
+                        }
                     }
-                    ring[t * WAVE + lane] = v;
-                    // sequence shorter than one window: a single minimiser over all its values
-                    if (i + 1 == L && p + 1 < wn) emit = true;
-                }
-            }
-            if (have_value) {
-                if (t + 1 == wn) {
-                    // block end: turn the raw values of this block into rightmost suffix minima, in place
-                    uint64_t sv = ring[(wn - 1) * WAVE + lane];
-                    uint32_t sp = wn - 1;
-                    spos[(wn - 1) * WAVE + lane] = sp;
+                    if (have_value) {
+                        if (t + 1 == wn) {
+                            // block end: turn the raw values of this block into rightmost suffix minima, in place
+                            uint64_t sv = ring[(wn - 1) * WAVE + lane];
+                            uint32_t sp = wn - 1;
+                            spos[(wn - 1) * WAVE + lane] = (uint8_t)sp;
 #pragma unroll
-                    for (int u = (int)wn - 2; u >= 1; --u) {
-                        const uint64_t x = ring[u * WAVE + lane];
-                        if (x < sv) { sv = x; sp = (uint32_t)u; }
-                        ring[u * WAVE + lane] = sv;
-                        spos[u * WAVE + lane] = sp;
+                            for (int u = (int)wn - 2; u >= 1; --u) {
+                                const uint64_t x = ring[u * WAVE + lane];
+                                if (x < sv) { sv = x; sp = (uint32_t)u; }
+                                ring[u * WAVE + lane] = sv;
+                                spos[u * WAVE + lane] = (uint8_t)sp;
+                            }
+                            t = 0; blk += wn;
+                        } else {
+                            ++t;
+                        }
                     }
-                    t = 0; blk += wn;
-                } else {
-                    ++t;
+                    const uint64_t mask = __ballot(emit);
+                    if (mask) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                        if (emit) {
+                            const uint32_t pos = (qhead + qcount + rank) & (QCAP - 1);
+                            qv[pos] = mv;
+                            qm[pos] = lane | (my_emitted << 6);
+                            ++my_emitted;
+                        }
+                        qcount += (uint32_t)__popcll(mask);
+                        if (qcount >= WAVE) {
+                            if (pending) probe_consume();
+                            probe_issue(WAVE);
+                        }
+                    }
                 }
-            }
-            const uint64_t mask = __ballot(emit);
-            if (mask) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                if (emit) {
-                    const uint32_t pos = (qhead + qcount + rank) & (QCAP - 1);
-                    qv[pos] = mv;
-                    qm[pos] = lane | (my_emitted << 6);
-                    ++my_emitted;
-                }
-                qcount += (uint32_t)__popcll(mask);
-                if (qcount >= WAVE) probe_round(WAVE);
             }
         }
     }
-    if (qcount) probe_round(qcount);
+    if (pending) probe_consume();
+    if (qcount) { probe_issue(qcount); if (pending) probe_consume(); }
 
+    __syncthreads();
     if (valid && MODE != MODE_EMPLACE) {
         a.num_hashes[r] = my_emitted;
-        if (MODE == MODE_FUSED)
+        if (MODE == MODE_FUSED) {
             for (uint32_t c = 0; c < a.C; ++c) {
                 a.counts[(size_t)r * a.C + c] = cnt[c * WAVE + lane];
                 a.unique[(size_t)r * a.C + c] = unq[c * WAVE + lane];
             }
+        }
     }
 }
 
@@ -977,7 +1042,7 @@ static hipError_t launch_k1_w(uint32_t W, const K1Args &a, size_t lds, hipStream
     }
 }
 static size_t k1_lds_bytes(uint32_t wn, uint32_t C, int mode) {
-    size_t b = (size_t)wn * WAVE * 8 + QCAP * 8 + QCAP * 4 + WAVE * 8 + (size_t)wn * WAVE * 4;
+    size_t b = (size_t)wn * WAVE * 8 + QCAP * 8 + QCAP * 4 + WAVE * 8 + (size_t)wn * WAVE;
     if (mode == MODE_FUSED) b += (size_t)2 * C * WAVE * 4;
     return b;
 }
