@@ -130,6 +130,7 @@ def main():
     out = None
     if rank == 0:
         k1_avg = k1_ms / max(k1_n, 1)
+        traffic = pmc_traffic(args.workload, n_reads, L)
         achieved = alg_bytes / (k1_avg * 1e-3) / 1e9 if k1_avg > 0 else 0.0
         out = {
             "metric": "classified reads/sec + achieved HBM GB/s vs roofline, 5 kb reads, 39 GB index",
@@ -150,7 +151,7 @@ def main():
                        "summary_counts": {"human": int(summary[0]), "microbial": int(summary[1]), "unclassified": int(summary[2])},
                        "setup_seconds": round(setup_s, 1)},
             "roofline": {"bound": "hbm", "kernel": "k_minimise_probe", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_avg,
                          "other_kernels_avg_ms": {"k_count_rows": k2_ms / max(k2_n, 1), "k_model_call": k3_ms / max(k3_n, 1),
                                                   "whole_chain": chain_ms / max(chain_n, 1)}},
@@ -164,6 +165,21 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def pmc_traffic(workload, n_reads, read_len):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of this same command (FETCH_SIZE and
+    WRITE_SIZE in separate passes, gfx950 correction applied; see profiles/rNN/pmc_traffic.json).  bench.py cannot run
+    the profiler on itself, so the most recent committed measurement for the same workload shape is reported."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f)).get(workload)
+        except (OSError, ValueError):
+            continue
+        if d and d.get("reads_per_launch") == n_reads and d.get("read_len") == read_len:
+            return d["traffic_bytes"]
+    return None
 
 
 def cpu_baseline(api, index, reads, res, n_reads, args, device, categories, b2c):

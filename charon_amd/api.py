@@ -61,7 +61,7 @@ class SynthReadsOut(C.Structure):
 # every symbol include/charon_hip.h declares
 EXPORTS = ["chn_index_create", "chn_index_upload_rows", "chn_index_device_words", "chn_index_download_rows",
            "chn_index_get_desc", "chn_index_destroy", "chn_model_default", "chn_stream_create", "chn_stream_destroy",
-           "chn_model_set", "chn_batch_submit", "chn_batch_wait", "chn_stream_sync", "chn_stream_profile",
+           "chn_model_set", "chn_batch_submit", "chn_batch_wait", "chn_stream_sync", "chn_classify_counts", "chn_stream_profile",
            "chn_stream_last_batch_bytes", "chn_synth_genomes", "chn_synth_fill_index", "chn_synth_plant", "chn_synth_reads",
            "chn_device_free", "chn_device_download", "chn_last_error", "chn_version"]
 
@@ -80,6 +80,7 @@ _L.chn_model_set.argtypes = [C.c_void_p, C.POINTER(Model)]
 _L.chn_batch_submit.argtypes = [C.c_void_p, C.POINTER(Batch)]
 _L.chn_batch_wait.argtypes = [C.c_void_p, C.POINTER(Result)]
 _L.chn_stream_sync.argtypes = [C.c_void_p]
+_L.chn_classify_counts.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 9
 _L.chn_stream_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
 _L.chn_stream_last_batch_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 _L.chn_synth_genomes.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
@@ -243,6 +244,15 @@ class Stream:
 
     def sync(self):
         _chk(_L.chn_stream_sync(self.h))
+
+    def classify_counts(self, num_hashes, counts, unique, lengths, mean_quality, compression):
+        n, Cn = len(num_hashes), self.C
+        a = [np.ascontiguousarray(x, dt) for x, dt in ((num_hashes, np.uint32), (counts, np.uint32), (unique, np.uint32),
+                                                       (lengths, np.uint32), (mean_quality, np.float32), (compression, np.float32))]
+        out = dict(probs=np.zeros((n, Cn), np.float64), call=np.zeros(n, np.uint8), conf=np.zeros(n, np.uint8))
+        _chk(_L.chn_classify_counts(self.h, n, *[x.ctypes.data for x in a], out["probs"].ctypes.data, out["call"].ctypes.data,
+                                    out["conf"].ctypes.data))
+        return out
 
     def profile(self, which, reset=False):
         ms, n = C.c_double(), C.c_uint64()

@@ -235,17 +235,17 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
                 for (uint32_t i = 0; i < 5; ++i)
                     if (i < a.h) {
                         const uint64_t *p = a.words + (rows_[i] - a.row_begin) * W;
+                        // non-temporal: a probed line is never reused, keep it from displacing the row/base lines in L2
                         if (W == 1) {
-                            pend[i][0] = p[0];
+                            pend[i][0] = __builtin_nontemporal_load(p);
                         } else if (W == 2) {
-                            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p);
-                            pend[i][0] = v.x; pend[i][W > 1 ? 1 : 0] = v.y;
+                            pend[i][0] = __builtin_nontemporal_load(p); pend[i][W > 1 ? 1 : 0] = __builtin_nontemporal_load(p + 1);
                         } else if (W == 3) {
-                            pend[i][0] = p[0]; pend[i][W > 1 ? 1 : 0] = p[1]; pend[i][W > 2 ? 2 : 0] = p[2];
+                            pend[i][0] = __builtin_nontemporal_load(p); pend[i][W > 1 ? 1 : 0] = __builtin_nontemporal_load(p + 1);
+                            pend[i][W > 2 ? 2 : 0] = __builtin_nontemporal_load(p + 2);
                         } else {
-                            const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(p);
-                            const ulonglong2 v1 = *reinterpret_cast<const ulonglong2 *>(p + 2);
-                            pend[i][0] = v0.x; pend[i][W > 1 ? 1 : 0] = v0.y; pend[i][W > 2 ? 2 : 0] = v1.x; pend[i][W > 3 ? 3 : 0] = v1.y;
+                            pend[i][0] = __builtin_nontemporal_load(p); pend[i][W > 1 ? 1 : 0] = __builtin_nontemporal_load(p + 1);
+                            pend[i][W > 2 ? 2 : 0] = __builtin_nontemporal_load(p + 2); pend[i][W > 3 ? 3 : 0] = __builtin_nontemporal_load(p + 3);
                         }
                     }
             }
@@ -1219,7 +1219,7 @@ extern "C" int chn_batch_wait(chn_stream *s, chn_result *r) {
         if (s->host_batch && r->num_hashes && r->counts && r->unique_counts && r->call && r->confidence && r->probabilities) {
             std::vector<double> p(C);
             for (uint64_t i = 0; i < n; ++i)
-                if (flags[i]) {
+                if (flags[i] || r->num_hashes[i] == 0) {
                     const uint32_t length = s->h_len1[i] + (s->h_len2.empty() ? 0u : s->h_len2[i]);
                     host_model_call(s->model, r->num_hashes[i], r->counts + i * C, r->unique_counts + i * C,
                                     s->h_mq.empty() ? 0.0f : s->h_mq[i], s->h_comp.empty() ? 0.0f : s->h_comp[i], length, p.data(),
@@ -1228,6 +1228,48 @@ extern "C" int chn_batch_wait(chn_stream *s, chn_result *r) {
                 }
         }
     }
+    return CHN_OK;
+}
+
+extern "C" int chn_classify_counts(chn_stream *s, uint64_t n, const uint32_t *num_hashes, const uint32_t *counts,
+                                   const uint32_t *unique_counts, const uint32_t *lengths, const float *mean_quality,
+                                   const float *compression, double *probabilities, uint8_t *call, uint8_t *confidence) {
+    if (!s || !num_hashes || !counts || !unique_counts || !lengths || !probabilities || !call || !confidence)
+        return fail(CHN_E_INVALID, "chn_classify_counts: null argument");
+    if (!s->model.set) return fail(CHN_E_STATE, "chn_classify_counts: no model set");
+    if (s->submitted) return fail(CHN_E_STATE, "chn_classify_counts: a batch is in flight");
+    if (n == 0) return CHN_OK;
+    if (n > s->cfg.max_reads) return fail(CHN_E_CAPACITY, "chn_classify_counts: more reads than the stream's max_reads");
+    HIPCHK(hipSetDevice(s->idx->d.device));
+    const uint64_t C = s->idx->d.num_categories;
+    int rc;
+    if ((rc = upload(s->d_len1, lengths, n * 4, s->stream))) return rc;
+    if (mean_quality && (rc = upload(s->d_mq, mean_quality, n * 4, s->stream))) return rc;
+    if (compression && (rc = upload(s->d_comp, compression, n * 4, s->stream))) return rc;
+    HIPCHK(hipMemcpyAsync(s->d_num_hashes.p, num_hashes, n * 4, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->d_counts.p, counts, n * C * 4, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->d_unique.p, unique_counts, n * C * 4, hipMemcpyHostToDevice, s->stream));
+    K3Args k3 = s->k3;
+    k3.num_hashes = s->d_num_hashes.as<uint32_t>(); k3.counts = s->d_counts.as<uint32_t>(); k3.unique = s->d_unique.as<uint32_t>();
+    k3.len1 = s->d_len1.as<uint32_t>(); k3.len2 = nullptr;
+    k3.mean_quality = mean_quality ? s->d_mq.as<float>() : nullptr; k3.compression = compression ? s->d_comp.as<float>() : nullptr;
+    k3.prob = s->d_prob.as<double>(); k3.call = s->d_call.as<uint8_t>(); k3.conf = s->d_conf.as<uint8_t>(); k3.flags = s->d_flags.as<uint8_t>();
+    k3.n_reads = (uint32_t)n;
+    hipLaunchKernelGGL(k_model_call, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s->stream, k3);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemcpy(probabilities, s->d_prob.p, n * C * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(call, s->d_call.p, n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(confidence, s->d_conf.p, n, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> flags(n);
+    HIPCHK(hipMemcpy(flags.data(), s->d_flags.p, n, hipMemcpyDeviceToHost));
+    std::vector<double> p(C);
+    for (uint64_t i = 0; i < n; ++i)
+        if (flags[i] || num_hashes[i] == 0) {  // borderline or NaN rows: host libm / host NaN sign
+            host_model_call(s->model, num_hashes[i], counts + i * C, unique_counts + i * C, mean_quality ? mean_quality[i] : 0.0f,
+                            compression ? compression[i] : 0.0f, lengths[i], p.data(), &call[i], &confidence[i]);
+            for (uint64_t c = 0; c < C; ++c) probabilities[i * C + c] = p[c];
+        }
     return CHN_OK;
 }
 

@@ -167,6 +167,14 @@ int chn_batch_submit(chn_stream *s, const chn_batch *b);   /* asynchronous on th
 int chn_batch_wait(chn_stream *s, chn_result *r);          /* blocks; fills / points `r` */
 int chn_stream_sync(chn_stream *s);
 
+/* Model + call only (k_model_call) on per-read counts the caller already holds -- used for reads that the
+ * Result state machine cached while the KDE models were still training (include/result.hpp:139-151,181-198)
+ * and that must be classified with the models as they are later.  All pointers are HOST arrays; outputs as in
+ * chn_result.  Replaces ReadEntry::dehost / ReadEntry::classify (include/read_entry.hpp:281-291). */
+int chn_classify_counts(chn_stream *s, uint64_t n_reads, const uint32_t *num_hashes, const uint32_t *counts,
+                        const uint32_t *unique_counts, const uint32_t *lengths, const float *mean_quality,
+                        const float *compression, double *probabilities, uint8_t *call, uint8_t *confidence);
+
 /* Per-kernel device time accumulated since the last reset (CHN_STREAM_PROFILE streams only).
  * which: 0 = minimise+probe kernel, 1 = count kernel, 2 = model+call kernel, 3 = whole batch chain. */
 int chn_stream_profile(chn_stream *s, int which, double *total_ms, uint64_t *launches, int reset);

@@ -1,0 +1,107 @@
+"""GPU tests (-m gpu) of the drop-in boundary: the C++14 `charon dehost` front end (charon_amd/bin/charon, linked only
+against the C ABI) must print the same TSV as the CPU oracle's dehost -- same rows in the same order (including the
+dropped-first-read quirk), every column textually identical except the probability, which may differ by <= 1e-6."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(util.ROOT, "tests", "golden")
+EXE = os.path.join(util.ROOT, "charon_amd", "bin", "charon")
+
+
+def run_cli(args, cwd, env_extra=None):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    p = subprocess.run([EXE, "dehost"] + args + ["--log", os.path.join(cwd, "charon.log")], cwd=cwd, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE)
+    return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+def assert_same_tsv(got, want, prob_tol=1e-6):
+    g, w = got.strip("\n").split("\n"), want.strip("\n").split("\n")
+    assert len(g) == len(w), (len(g), len(w))
+    for a, b in zip(g, w):
+        if a == b:
+            continue
+        fa, fb = a.split("\t"), b.split("\t")
+        assert fa[:8] == fb[:8], (a, b)
+        da, db = fa[8].strip().split(" "), fb[8].strip().split(" ")
+        assert len(da) == len(db)
+        for x, y in zip(da, db):
+            xs, ys = x.split(":"), y.split(":")
+            assert xs[:4] == ys[:4], (a, b)
+            if xs[4] != ys[4]:
+                assert abs(float(xs[4]) - float(ys[4])) <= prob_tol, (a, b)
+
+
+def test_cli_golden_cfg1(tmp_path):
+    assert os.path.exists(EXE), "host front end not built"
+    fq = os.path.join(G, "cfg1_reads.fastq.gz")
+    rc, out, err = run_cli(["--db", os.path.join(G, "cfg1.idx"), fq], str(tmp_path))
+    assert rc == 0, err
+    assert_same_tsv(out, open(os.path.join(G, "cfg1_expected.tsv")).read())
+    assert out.split("\n")[0].split("\t")[1] == "r1"  # r0 is dropped (no --extract)
+    # small GPU batches, more host threads: identical rows
+    rc, out2, err = run_cli(["--db", os.path.join(G, "cfg1.idx"), "-t", "4", fq], str(tmp_path), {"CHARON_BATCH_READS": "37"})
+    assert rc == 0 and out2 == out
+    # --extract drives the training cache (num_reads_to_fit 20 -> models retrain, cached reads re-classified)
+    rc, out3, err = run_cli(["--db", os.path.join(G, "cfg1.idx"), "--extract", "microbial", "--num_reads_to_fit", "20", fq], str(tmp_path),
+                            {"CHARON_BATCH_READS": "64"})
+    assert rc == 0, err
+    assert_same_tsv(out3, open(os.path.join(G, "cfg1_expected_extract.tsv")).read())
+
+
+def test_cli_paired_fasta_and_thresholds(tmp_path, oracle_lib):
+    r = util.rng(21)
+    gs = [util.random_seq(r, 6000) for _ in range(3)]
+    for i, g in enumerate(gs):
+        with open(tmp_path / ("g%d.fa" % i), "w") as f:
+            f.write(">g%d\n%s\n" % (i, g.decode()))
+    oidx = oracle_lib.Index.from_fasta([(str(tmp_path / "g0.fa"), "human"), (str(tmp_path / "g1.fa"), "bacteria"),
+                                        (str(tmp_path / "g2.fa"), "human")], ["bacteria", "human"])
+    oidx.store(str(tmp_path / "p.idx"))
+    m1 = util.sample_reads(r, gs, 300, (100, 250), sub_rate=0.02)
+    m2 = util.sample_reads(r, gs, 300, (100, 250), sub_rate=0.02)
+    m1[5] = m1[5][:60] + b"NNNRY" + m1[5][65:]
+    for name, mates, tag in (("r_1.fastq", m1, "/1"), ("r_2.fastq", m2, "/2")):
+        with open(tmp_path / name, "w") as f:
+            for i, s in enumerate(mates):
+                q = "".join(chr(33 + int(x)) for x in r.integers(5, 41, len(s)))
+                f.write("@read%d%s\n%s\n+\n%s\n" % (i, tag, s.decode(), q))
+    want = oidx.dehost_files(str(tmp_path / "r_1.fastq"), str(tmp_path / "r_2.fastq"))
+    rc, out, err = run_cli(["--db", str(tmp_path / "p"), str(tmp_path / "r_1.fastq"), str(tmp_path / "r_2.fastq")], str(tmp_path))
+    assert rc == 0, err
+    assert_same_tsv(out, want)
+    assert sum(1 for x in out.split("\n") if x.startswith("C\t")) > 20
+    # single-end, FASTA input (no qualities -> never classified), gz input, non-default thresholds
+    with gzip.open(tmp_path / "s.fasta.gz", "wt") as f:
+        for i, s in enumerate(m1):
+            f.write(">s%d some description\n%s\n" % (i, s.decode()))
+    want = oidx.dehost_files(str(tmp_path / "s.fasta.gz"))
+    rc, out, err = run_cli(["--db", str(tmp_path / "p.idx"), str(tmp_path / "s.fasta.gz")], str(tmp_path))
+    assert rc == 0, err
+    assert_same_tsv(out, want)
+    assert all(x.startswith("U\t") for x in out.strip().split("\n"))
+    want = oidx.dehost_files(str(tmp_path / "r_1.fastq"), min_quality=0.0, confidence=200)
+    rc, out, err = run_cli(["--db", str(tmp_path / "p.idx"), "--min_quality", "0", "--confidence", "200", str(tmp_path / "r_1.fastq")], str(tmp_path))
+    assert rc == 0, err
+    assert_same_tsv(out, want)
+    oidx.free()
+
+
+def test_cli_errors(tmp_path):
+    fq = os.path.join(G, "cfg1_reads.fastq.gz")
+    rc, out, err = run_cli(["--db", os.path.join(G, "cfg1.idx"), "--threads", "256", fq], str(tmp_path))
+    assert rc != 0 and out == ""
+    rc, out, err = run_cli(["--db", os.path.join(G, "nope.idx"), fq], str(tmp_path))
+    assert rc != 0
+    # rejected --dist is logged and the exit status stays 0 (the reference's callback drops the return value)
+    rc, out, err = run_cli(["--db", os.path.join(G, "cfg1.idx"), "--dist", "weibull", fq], str(tmp_path))
+    assert rc == 0 and out == ""
+    assert "Supported distributions" in open(tmp_path / "charon.log").read()

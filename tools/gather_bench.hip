@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void k_gather(const uint64_t *tab, uint64_t ro
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
             if (BYTES == 8) acc ^= tab[r[j]];
+            else if (BYTES == 128) { acc ^= tab[(r[j] & ~15ULL)]; acc ^= tab[(r[j] & ~15ULL) + 8]; }  // both 64-B halves of one 128-B line
             else { ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(tab + 2 * r[j]); acc ^= v.x & v.y; }
         }
     }
@@ -42,7 +43,7 @@ int main(int argc, char **argv) {
     hipMemset(tab, 0x5a, bytes);
     if (argc > 2) {  // single configuration (for rocprofv3 --pmc): <GB> <bytes 8|16> : 16 waves/CU, ilp 3
         int blocks = 256 * 16 / 4;
-        double g = atoi(argv[2]) == 8 ? run<8, 3>(tab, bytes / 8, out, blocks, 1000) : run<16, 3>(tab, bytes / 16, out, blocks, 1000);
+        double g = atoi(argv[2]) == 8 ? run<8, 3>(tab, bytes / 8, out, blocks, 1000) : atoi(argv[2]) == 128 ? run<128, 3>(tab, bytes / 8, out, blocks, 1000) : run<16, 3>(tab, bytes / 16, out, blocks, 1000);
         printf("table %.1f GB %dB ilp3: %.1f Ggather/s, gathers in timed launch: %llu\n", gb, atoi(argv[2]), g, (unsigned long long)blocks * 256 * 1000 * 3);
         return 0;
     }
