@@ -26,6 +26,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <string>
 #include <vector>
@@ -894,7 +895,8 @@ static void host_model_call(const HostModel &M, uint32_t nh, const uint32_t *cnt
         uprops[c] = (float)uq[c] / (float)nh;
         const float x = uprops[c];
         float p_err;
-        if (std::isnan(x)) p_err = x; else if (x < 0.0f) p_err = 0.0f; else p_err = std::exp(std::log(M.rate) - M.rate * x);
+        // statslib: NaN in -> quiet_NaN out
+        if (std::isnan(x)) p_err = std::numeric_limits<float>::quiet_NaN(); else if (x < 0.0f) p_err = 0.0f; else p_err = std::exp(std::log(M.rate) - M.rate * x);
         float p_pos = host_kde_prob(M.pos[c], M.h_pos, x);
         const float p_neg = host_kde_prob(M.neg[c], M.h_neg, x);
         if (x == 1.0f) p_pos = 1.0f;

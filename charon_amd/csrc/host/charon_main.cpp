@@ -575,7 +575,7 @@ class Result {
         if (es.empty()) return;
         if (device_model_version_ != training_.version) push_model_to_device();
         const size_t C = meta_.categories.size();
-        const size_t chunk = 1 << 16;
+        const size_t chunk = (size_t)std::min<uint64_t>(1 << 16, opt_.batch_reads);  // <= the stream's max_reads
         for (size_t b = 0; b < es.size(); b += chunk) {
             const size_t n = std::min(chunk, es.size() - b);
             std::vector<uint32_t> nh(n), cnt(n * C), unq(n * C), len(n);
