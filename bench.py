@@ -66,6 +66,7 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
     import charon_amd.api as api
+    from charon_amd import shard
     wl = dict(WORKLOADS[args.workload])
     if args.reads_per_step:
         wl["reads"] = args.reads_per_step
@@ -81,7 +82,9 @@ def main():
     index.synth_fill(43, wl["fill"])
     genomes = api.synth_genomes(local, 43, B, wl["genome_len"])
     index.synth_plant(genomes, B, wl["genome_len"], list(range(B)))
-    reads = api.synth_reads(local, 42 + rank, genomes, B, wl["genome_len"], n_reads, L, L, 0.05, 0.10, 40.0)
+    # weak scaling: rank r classifies global reads [r*n, (r+1)*n) of one seeded read set (charon_amd/shard.py)
+    lo, hi = shard.shard_range(n_reads * world, rank, world)
+    reads = api.synth_reads(local, 42, genomes, B, wl["genome_len"], hi - lo, L, L, 0.05, 0.10, 40.0, first_read_id=lo)
     stream = api.Stream(index, n_reads, reads.n_bases, profile=True)
     stream.set_model(api.default_model(2, 0))
     setup_s = time.time() - t_setup
@@ -114,11 +117,9 @@ def main():
 
     # summary counters (ResultSummary, include/result.hpp:18-25): the one collective of the read-sharded mode
     call = api.device_download(local, res.call, n_reads, np.uint8)
-    summary = np.array([(call == 0).sum(), (call == 1).sum(), (call == 255).sum()], dtype=np.int64)
+    summary = shard.summary_counts(call, 2)
     if world > 1:
-        ts = torch.tensor(summary, device="cuda")
-        dist.all_reduce(ts)
-        summary = ts.cpu().numpy()
+        summary = shard.merge_summary(summary, dist, torch.device("cuda", local))
 
     k1_ms, k1_n = stream.profile(0)
     k2_ms, k2_n = stream.profile(1)

@@ -86,7 +86,7 @@ _L.chn_stream_last_batch_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.
 _L.chn_synth_genomes.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
 _L.chn_synth_fill_index.argtypes = [C.c_void_p, C.c_uint64, C.c_double]
 _L.chn_synth_plant.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p]
-_L.chn_synth_reads.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
+_L.chn_synth_reads.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                C.c_double, C.c_double, C.c_float, C.POINTER(SynthReadsOut)]
 _L.chn_device_free.argtypes = [C.c_int, C.c_void_p]
 _L.chn_device_download.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
@@ -277,9 +277,9 @@ def synth_genomes(device, seed, n_genomes, genome_len):
 
 
 def synth_reads(device, seed, dev_genomes, n_genomes, genome_len, n_reads, len_min, len_max, sub_rate=0.05,
-                random_fraction=0.1, mean_quality=40.0):
+                random_fraction=0.1, mean_quality=40.0, first_read_id=0):
     out = SynthReadsOut()
-    _chk(_L.chn_synth_reads(device, seed, dev_genomes, n_genomes, genome_len, n_reads, len_min, len_max, sub_rate,
+    _chk(_L.chn_synth_reads(device, seed, dev_genomes, n_genomes, genome_len, first_read_id, n_reads, len_min, len_max, sub_rate,
                             random_fraction, mean_quality, C.byref(out)))
     return out
 

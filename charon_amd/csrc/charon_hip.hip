@@ -649,18 +649,18 @@ __global__ void k_synth_fill(uint64_t *words, uint64_t n_rows, uint32_t W, uint3
 }
 struct SynthReadsArgs {
     const uint32_t *genomes;
-    uint64_t n_genomes, genome_len, seed, n_reads;
+    uint64_t n_genomes, genome_len, seed, n_reads, first_id;
     uint32_t len_min, len_max, sub_thr32, rand_thr32;
     uint32_t *bases;
     const uint64_t *off;
     const uint32_t *len;
 };
-__global__ void k_synth_read_layout(uint64_t seed, uint64_t n_reads, uint32_t len_min, uint32_t len_max, uint32_t *len) {
+__global__ void k_synth_read_layout(uint64_t seed, uint64_t first_id, uint64_t n_reads, uint32_t len_min, uint32_t len_max, uint32_t *len) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i < n_reads) {
         uint32_t L = len_min;
         if (len_max > len_min) {  // log-uniform in [len_min, len_max]
-            const double u = (double)(mix64(seed ^ (i * 0xA24BAED4963EE407ULL)) >> 11) * (1.0 / 9007199254740992.0);
+            const double u = (double)(mix64(seed ^ ((first_id + i) * 0xA24BAED4963EE407ULL)) >> 11) * (1.0 / 9007199254740992.0);
             L = (uint32_t)(exp(log((double)len_min) + u * (log((double)len_max) - log((double)len_min))));
             L = L < len_min ? len_min : (L > len_max ? len_max : L);
         }
@@ -681,7 +681,7 @@ __global__ void k_synth_reads(const SynthReadsArgs a) {
     if (read >= a.n_reads) return;
     const uint32_t L = a.len[read];
     const uint32_t nd = (L + 63) / 64 * 4;
-    const uint64_t rs = mix64(a.seed ^ (read * 0x9FB21C651E98DF25ULL));
+    const uint64_t rs = mix64(a.seed ^ ((a.first_id + read) * 0x9FB21C651E98DF25ULL));
     const bool is_random = a.n_genomes == 0 || (uint32_t)(rs >> 32) < a.rand_thr32;
     const uint64_t g = a.n_genomes ? (mix64(rs + 1) % a.n_genomes) : 0;
     const uint64_t span = a.genome_len > L ? a.genome_len - L : 1;
@@ -1346,7 +1346,7 @@ extern "C" int chn_synth_plant(chn_index *idx, const uint32_t *dev_bases2, uint6
     return CHN_OK;
 }
 extern "C" int chn_synth_reads(int device, uint64_t seed, const uint32_t *dev_genomes, uint64_t n_genomes, uint64_t genome_len,
-                               uint64_t n_reads, uint32_t read_len_min, uint32_t read_len_max, double sub_rate, double random_fraction,
+                               uint64_t first_read_id, uint64_t n_reads, uint32_t read_len_min, uint32_t read_len_max, double sub_rate, double random_fraction,
                                float mean_quality, chn_synth_reads_out *out) {
     if (!out || n_reads == 0 || read_len_min == 0 || read_len_max < read_len_min) return fail(CHN_E_INVALID, "chn_synth_reads: bad argument");
     if (n_genomes && (!dev_genomes || genome_len < read_len_max)) return fail(CHN_E_INVALID, "genomes shorter than reads");
@@ -1359,7 +1359,7 @@ extern "C" int chn_synth_reads(int device, uint64_t seed, const uint32_t *dev_ge
     HIPCHK(hipMalloc((void **)&out->compression, n_reads * 4));
     HIPCHK(hipMalloc((void **)&d_total, 8));
     const dim3 g1((uint32_t)((n_reads + 255) / 256)), b1(256);
-    hipLaunchKernelGGL(k_synth_read_layout, g1, b1, 0, 0, seed, n_reads, read_len_min, read_len_max, out->seg1_length);
+    hipLaunchKernelGGL(k_synth_read_layout, g1, b1, 0, 0, seed, first_read_id, n_reads, read_len_min, read_len_max, out->seg1_length);
     uint64_t total = 0;
     if (read_len_min == read_len_max) {
         const uint64_t pad = ((uint64_t)read_len_min + 63) & ~63ULL;
@@ -1378,7 +1378,7 @@ extern "C" int chn_synth_reads(int device, uint64_t seed, const uint32_t *dev_ge
     hipLaunchKernelGGL(k_fill_f32, g1, b1, 0, 0, out->mean_quality, n_reads, mean_quality);
     hipLaunchKernelGGL(k_fill_f32, g1, b1, 0, 0, out->compression, n_reads, 0.3f);
     SynthReadsArgs a;
-    a.genomes = dev_genomes; a.n_genomes = n_genomes; a.genome_len = genome_len; a.seed = seed; a.n_reads = n_reads;
+    a.genomes = dev_genomes; a.n_genomes = n_genomes; a.genome_len = genome_len; a.seed = seed; a.n_reads = n_reads; a.first_id = first_read_id;
     a.len_min = read_len_min; a.len_max = read_len_max;
     a.sub_thr32 = (uint32_t)std::min<double>(4294967295.0, sub_rate * 4294967296.0);
     a.rand_thr32 = (uint32_t)std::min<double>(4294967295.0, random_fraction * 4294967296.0);

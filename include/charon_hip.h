@@ -200,8 +200,10 @@ typedef struct chn_synth_reads_out {
     float *compression;
     uint64_t n_bases;
 } chn_synth_reads_out;
+/* `first_read_id`: global index of read 0 of this batch; a read's content depends only on (seed, global index), so
+ * the union of the batches of N ranks equals one batch of N times the size. */
 int chn_synth_reads(int device, uint64_t seed, const uint32_t *dev_genomes, uint64_t n_genomes, uint64_t genome_len,
-                    uint64_t n_reads, uint32_t read_len_min, uint32_t read_len_max, double sub_rate,
+                    uint64_t first_read_id, uint64_t n_reads, uint32_t read_len_min, uint32_t read_len_max, double sub_rate,
                     double random_fraction, float mean_quality, chn_synth_reads_out *out);
 int chn_device_free(int device, void *ptr);
 int chn_device_download(int device, void *host_dst, const void *dev_src, uint64_t bytes);

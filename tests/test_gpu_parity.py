@@ -179,7 +179,7 @@ def test_device_fabricated_workload_matches_oracle(api, oracle_lib):
     for b, gs in enumerate(genomes):
         oidx.emplace_many(np.unique(oracle_lib.minimisers(gs.decode())), b)
     assert np.array_equal(oidx.words(), words)
-    rd = api.synth_reads(0, 42, gen, n_gen, glen, 500, 300, 3000, 0.05, 0.1, 40.0)
+    rd = api.synth_reads(0, 42, gen, n_gen, glen, 500, 300, 3000, 0.05, 0.1, 40.0, first_read_id=1000)
     lens = api.device_download(0, rd.seg1_length, 500 * 4, np.uint32)
     offs = api.device_download(0, rd.seg1_offset, 500 * 8, np.uint64)
     assert lens.min() >= 300 and lens.max() <= 3000 and (offs % 64 == 0).all()

@@ -1,0 +1,61 @@
+"""CPU test of the N > 1 path: two gloo ranks each classify their shard of one read set (with the CPU oracle standing in
+for the device, since there is no GPU here), merge the summary counters with the same all-reduce bench.py uses, and
+must reproduce the single-process result.  The data path itself has no collective (reads are independent units)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from tests import util
+
+
+def _worker(rank, world, initfile, outdir):
+    import torch.distributed as dist
+    from charon_amd import shard
+    from oracle import pyoracle as po
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    r = util.rng(77)
+    gs = [util.random_seq(r, 5000), util.random_seq(r, 5000)]
+    oidx = util.build_oracle_index(po, [[g] for g in gs], [0, 1], ["host", "microbial"])
+    reads = util.sample_reads(r, gs, 101, (200, 600))  # odd count: shards differ in size
+    lo, hi = shard.shard_range(len(reads), rank, world)
+    seqs, offs, _ = util.concat(reads[lo:hi])
+    o = oidx.process_reads(seqs, offs)
+    merged = shard.merge_summary(shard.summary_counts(o["call"], 2), dist)
+    np.save(os.path.join(outdir, "r%d.npy" % rank), np.concatenate([[lo, hi], merged]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_summary_merge(oracle_lib):
+    import torch.multiprocessing as mp
+    from charon_amd import shard
+    with tempfile.TemporaryDirectory() as d:
+        initfile = os.path.join(d, "init")
+        mp.spawn(_worker, args=(2, initfile, d), nprocs=2, join=True)
+        a, b = np.load(os.path.join(d, "r0.npy")), np.load(os.path.join(d, "r1.npy"))
+    assert (a[0], a[1], b[0], b[1]) == (0, 51, 51, 101)
+    assert np.array_equal(a[2:], b[2:])
+    # single-process reference
+    r = util.rng(77)
+    gs = [util.random_seq(r, 5000), util.random_seq(r, 5000)]
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [0, 1], ["host", "microbial"])
+    reads = util.sample_reads(r, gs, 101, (200, 600))
+    seqs, offs, _ = util.concat(reads)
+    want = shard.summary_counts(oidx.process_reads(seqs, offs)["call"], 2)
+    assert np.array_equal(a[2:], want) and want.sum() == 101
+    oidx.free()
+
+
+def test_shard_range_properties():
+    from charon_amd import shard
+    for total in (0, 1, 7, 64, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [shard.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard.shard_range(10, 2, 2)
