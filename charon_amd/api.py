@@ -185,7 +185,7 @@ class Stream:
         self.h = C.c_void_p()
         _chk(_L.chn_stream_create(index.h, C.byref(cfg), C.byref(self.h)))
         self.C = index.desc.num_categories
-        self._keep = None
+        self._fifo = []  # (n_reads, keep-alive host arrays) of the batches in flight
 
     def set_model(self, model):
         _chk(_L.chn_model_set(self.h, C.byref(model)))
@@ -212,9 +212,8 @@ class Stream:
         b.seg2_length = ptr(packed.get("seg2_length"), np.uint32)
         b.mean_quality = ptr(mean_quality, np.float32)
         b.compression = ptr(compression, np.float32)
-        self._keep = keep
-        self._n = n
         _chk(_L.chn_batch_submit(self.h, C.byref(b)))
+        self._fifo.append((n, keep))
 
     def submit_device(self, n_reads, n_bases, bases2, seg1_offset, seg1_length, mean_quality=None, compression=None,
                       nmask=None, seg2_offset=None, seg2_length=None):
@@ -222,24 +221,25 @@ class Stream:
         b.struct_size, b.on_device, b.n_reads, b.n_bases = C.sizeof(Batch), 1, n_reads, n_bases
         b.bases2, b.nmask, b.seg1_offset, b.seg1_length = bases2, nmask, seg1_offset, seg1_length
         b.seg2_offset, b.seg2_length, b.mean_quality, b.compression = seg2_offset, seg2_length, mean_quality, compression
-        self._n = n_reads
         _chk(_L.chn_batch_submit(self.h, C.byref(b)))
+        self._fifo.append((n_reads, None))
 
     def wait_host(self):
-        n, Cn = self._n, self.C
+        n, Cn = self._fifo[0][0], self.C
         out = dict(num_hashes=np.zeros(n, np.uint32), counts=np.zeros((n, Cn), np.uint32), unique=np.zeros((n, Cn), np.uint32),
                    probs=np.zeros((n, Cn), np.float64), call=np.zeros(n, np.uint8), conf=np.zeros(n, np.uint8),
                    flags=np.zeros(n, np.uint8))
         r = Result(C.sizeof(Result), 0, out["num_hashes"].ctypes.data, out["counts"].ctypes.data, out["unique"].ctypes.data,
                    out["probs"].ctypes.data, out["call"].ctypes.data, out["conf"].ctypes.data, out["flags"].ctypes.data)
         _chk(_L.chn_batch_wait(self.h, C.byref(r)))
-        self._keep = None
+        self._fifo.pop(0)
         return out
 
     def wait_device(self):
         r = Result()
         r.struct_size, r.on_device = C.sizeof(Result), 1
         _chk(_L.chn_batch_wait(self.h, C.byref(r)))
+        self._fifo.pop(0)
         return r
 
     def sync(self):

@@ -754,29 +754,36 @@ struct HostModel {  // deep copy of chn_model
     uint8_t min_hits = 0, paired = 0, host_index = 0;
 };
 
+// Per-batch state.  Two slots let batch i+1 be submitted while batch i's model+call kernel (fp64 VALU work on a side
+// stream) is still running: that kernel then overlaps the HBM-bound minimise+probe kernel of the next batch.
+struct Slot {
+    DevBuf d_num_hashes, d_counts, d_unique, d_prob, d_call, d_conf, d_flags, d_acc;
+    DevBuf d_len1, d_len2, d_mq, d_comp;  // staging of the small per-read arrays of host batches (read by k_model_call)
+    const uint32_t *len1 = nullptr, *len2 = nullptr;
+    const float *mq = nullptr, *comp = nullptr;
+    uint64_t n_reads = 0;
+    bool host_batch = false, model_ran = false;
+    std::vector<uint32_t> h_len1, h_len2;
+    std::vector<float> h_mq, h_comp;
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // K1 0-1, K2 2-3, K3 4-5, chain 6-7
+    hipEvent_t k2_done = nullptr, done = nullptr;
+    bool ev_used[4] = {false, false, false, false};
+};
+
 struct chn_stream {
     chn_index *idx = nullptr;
     chn_stream_cfg cfg;
-    hipStream_t stream = nullptr;
-    // staging of host batches
-    DevBuf d_bases, d_nmask, d_off1, d_off2, d_len1, d_len2, d_mq, d_comp;
-    // per-batch device state
-    DevBuf d_order, d_hist, d_num_hashes, d_counts, d_unique, d_prob, d_call, d_conf, d_flags, d_rows, d_model, d_acc;
-    // current batch view (device pointers)
-    const uint32_t *bases = nullptr, *nmask = nullptr, *len1 = nullptr, *len2 = nullptr;
-    const uint64_t *off1 = nullptr, *off2 = nullptr;
-    const float *mq = nullptr, *comp = nullptr;
-    uint64_t n_reads = 0, n_bases = 0;
-    bool submitted = false;
+    hipStream_t stream = nullptr;   // uploads, ordering, minimise+probe, count
+    hipStream_t stream2 = nullptr;  // model+call
+    // staging of host batches (large arrays; reused by the next batch in stream order)
+    DevBuf d_bases, d_nmask, d_off1, d_off2;
+    DevBuf d_order, d_hist, d_rows, d_model;
+    Slot slot[2];
+    int head = 0;      // slot of the next submit
+    int inflight = 0;  // batches submitted and not yet waited for (FIFO)
     HostModel model;
     K3Args k3;
-    // host copies for the borderline re-evaluation
-    std::vector<uint32_t> h_len1, h_len2;
-    std::vector<float> h_mq, h_comp;
-    bool host_batch = false;
     // profiling
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool ev_used[4] = {false, false, false, false};
     double prof_ms[4] = {0, 0, 0, 0};
     uint64_t prof_n[4] = {0, 0, 0, 0};
     uint64_t last_bytes = 0, last_min = 0;
@@ -944,19 +951,23 @@ extern "C" int chn_stream_create(chn_index *idx, const chn_stream_cfg *cfg, chn_
     if (!s) return fail(CHN_E_NOMEM, "host allocation failed");
     s->idx = idx; s->cfg = *cfg;
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete s; return fail(CHN_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
-    for (int i = 0; i < 8; ++i) {
-        e = hipEventCreate(&s->ev[i]);
-        if (e != hipSuccess) { delete s; return fail(CHN_E_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
-    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking);
+    if (e != hipSuccess) { chn_stream_destroy(s); return fail(CHN_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
     const uint64_t n = cfg->max_reads, C = idx->d.num_categories;
     int rc = CHN_OK;
-    if ((rc = s->d_order.ensure(n * 4)) || (rc = s->d_hist.ensure(256 * 4)) || (rc = s->d_num_hashes.ensure(n * 4)) ||
-        (rc = s->d_counts.ensure(n * C * 4)) || (rc = s->d_unique.ensure(n * C * 4)) || (rc = s->d_prob.ensure(n * C * 8)) ||
-        (rc = s->d_call.ensure(n)) || (rc = s->d_conf.ensure(n)) || (rc = s->d_flags.ensure(n)) || (rc = s->d_acc.ensure(16))) {
-        chn_stream_destroy(s);
-        return rc;
+    for (Slot &sl : s->slot) {
+        for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&sl.ev[i]);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.k2_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
+        if (e != hipSuccess) { chn_stream_destroy(s); return fail(CHN_E_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
+        if ((rc = sl.d_num_hashes.ensure(n * 4)) || (rc = sl.d_counts.ensure(n * C * 4)) || (rc = sl.d_unique.ensure(n * C * 4)) ||
+            (rc = sl.d_prob.ensure(n * C * 8)) || (rc = sl.d_call.ensure(n)) || (rc = sl.d_conf.ensure(n)) || (rc = sl.d_flags.ensure(n)) ||
+            (rc = sl.d_acc.ensure(16))) {
+            chn_stream_destroy(s);
+            return rc;
+        }
     }
+    if ((rc = s->d_order.ensure(n * 4)) || (rc = s->d_hist.ensure(256 * 4))) { chn_stream_destroy(s); return rc; }
     const bool fused = idx->single_bin_categories && C <= 8 && idx->d.bin_words == 1;
     if (!fused) {
         if ((rc = s->d_rows.ensure(cfg->max_bases * idx->d.bin_words * 8))) { chn_stream_destroy(s); return rc; }
@@ -968,11 +979,18 @@ extern "C" int chn_stream_create(chn_index *idx, const chn_stream_cfg *cfg, chn_
 extern "C" int chn_stream_destroy(chn_stream *s) {
     if (!s) return CHN_OK;
     (void)hipSetDevice(s->idx->d.device);
-    if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
-    for (int i = 0; i < 8; ++i) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
-    DevBuf *bufs[] = {&s->d_bases, &s->d_nmask, &s->d_off1, &s->d_off2, &s->d_len1, &s->d_len2, &s->d_mq, &s->d_comp, &s->d_order,
-                      &s->d_hist, &s->d_num_hashes, &s->d_counts, &s->d_unique, &s->d_prob, &s->d_call, &s->d_conf, &s->d_flags,
-                      &s->d_rows, &s->d_model, &s->d_acc};
+    if (s->stream) { (void)hipStreamSynchronize(s->stream); }
+    if (s->stream2) { (void)hipStreamSynchronize(s->stream2); (void)hipStreamDestroy(s->stream2); }
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    for (Slot &sl : s->slot) {
+        for (int i = 0; i < 8; ++i) if (sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
+        if (sl.k2_done) (void)hipEventDestroy(sl.k2_done);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        DevBuf *bufs[] = {&sl.d_num_hashes, &sl.d_counts, &sl.d_unique, &sl.d_prob, &sl.d_call, &sl.d_conf, &sl.d_flags, &sl.d_acc,
+                          &sl.d_len1, &sl.d_len2, &sl.d_mq, &sl.d_comp};
+        for (DevBuf *b : bufs) b->release();
+    }
+    DevBuf *bufs[] = {&s->d_bases, &s->d_nmask, &s->d_off1, &s->d_off2, &s->d_order, &s->d_hist, &s->d_rows, &s->d_model};
     for (DevBuf *b : bufs) b->release();
     delete s;
     return CHN_OK;
@@ -1012,7 +1030,9 @@ extern "C" int chn_model_set(chn_stream *s, const chn_model *m) {
         k.neg_off[c] = (uint32_t)flat.size(); k.neg_n[c] = (uint32_t)M.neg[c].size();
         flat.insert(flat.end(), M.neg[c].begin(), M.neg[c].end());
     }
+    if (s->inflight) return fail(CHN_E_STATE, "chn_model_set: batches are in flight");
     HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream2));
     int rc = s->d_model.ensure(std::max<size_t>(flat.size() * 4, 4));
     if (rc) return rc;
     HIPCHK(hipMemcpy(s->d_model.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
@@ -1058,7 +1078,7 @@ static int upload(DevBuf &buf, const void *src, size_t bytes, hipStream_t st) {
 
 extern "C" int chn_batch_submit(chn_stream *s, const chn_batch *b) {
     if (!s || !b || b->struct_size != sizeof(chn_batch)) return fail(CHN_E_INVALID, "chn_batch_submit: bad argument");
-    if (s->submitted) return fail(CHN_E_STATE, "previous batch not waited for");
+    if (s->inflight >= 2) return fail(CHN_E_STATE, "two batches already in flight: call chn_batch_wait first");
     if (b->n_reads == 0) return fail(CHN_E_INVALID, "empty batch");
     if (b->n_reads > s->cfg.max_reads || b->n_bases > s->cfg.max_bases) return fail(CHN_E_CAPACITY, "batch exceeds stream capacity");
     if (!b->bases2 || !b->seg1_offset || !b->seg1_length) return fail(CHN_E_INVALID, "missing batch arrays");
@@ -1070,7 +1090,10 @@ extern "C" int chn_batch_submit(chn_stream *s, const chn_batch *b) {
     const bool paired = b->seg2_offset != nullptr;
     const uint32_t W = (uint32_t)d.bin_words, C = d.num_categories;
     const bool fused = s->idx->single_bin_categories && C <= 8 && W == 1;
-    s->host_batch = !b->on_device;
+    Slot &sl = s->slot[s->head];
+    sl.host_batch = !b->on_device;
+    const uint32_t *bases, *nmask;
+    const uint64_t *off1, *off2;
     if (!b->on_device) {
         // host-side validation of operand shapes before anything is launched
         for (uint64_t i = 0; i < n; ++i) {
@@ -1085,34 +1108,34 @@ extern "C" int chn_batch_submit(chn_stream *s, const chn_batch *b) {
         int rc;
         if ((rc = upload(s->d_bases, b->bases2, b->n_bases / 4, s->stream))) return rc;
         if (b->nmask && (rc = upload(s->d_nmask, b->nmask, b->n_bases / 8, s->stream))) return rc;
-        if ((rc = upload(s->d_off1, b->seg1_offset, n * 8, s->stream)) || (rc = upload(s->d_len1, b->seg1_length, n * 4, s->stream))) return rc;
-        if (paired && ((rc = upload(s->d_off2, b->seg2_offset, n * 8, s->stream)) || (rc = upload(s->d_len2, b->seg2_length, n * 4, s->stream)))) return rc;
-        if (b->mean_quality && (rc = upload(s->d_mq, b->mean_quality, n * 4, s->stream))) return rc;
-        if (b->compression && (rc = upload(s->d_comp, b->compression, n * 4, s->stream))) return rc;
-        s->bases = s->d_bases.as<uint32_t>();
-        s->nmask = b->nmask ? s->d_nmask.as<uint32_t>() : nullptr;
-        s->off1 = s->d_off1.as<uint64_t>(); s->len1 = s->d_len1.as<uint32_t>();
-        s->off2 = paired ? s->d_off2.as<uint64_t>() : nullptr; s->len2 = paired ? s->d_len2.as<uint32_t>() : nullptr;
-        s->mq = b->mean_quality ? s->d_mq.as<float>() : nullptr;
-        s->comp = b->compression ? s->d_comp.as<float>() : nullptr;
-        s->h_len1.assign(b->seg1_length, b->seg1_length + n);
-        if (paired) s->h_len2.assign(b->seg2_length, b->seg2_length + n); else s->h_len2.clear();
-        if (b->mean_quality) s->h_mq.assign(b->mean_quality, b->mean_quality + n); else s->h_mq.clear();
-        if (b->compression) s->h_comp.assign(b->compression, b->compression + n); else s->h_comp.clear();
+        if ((rc = upload(s->d_off1, b->seg1_offset, n * 8, s->stream)) || (rc = upload(sl.d_len1, b->seg1_length, n * 4, s->stream))) return rc;
+        if (paired && ((rc = upload(s->d_off2, b->seg2_offset, n * 8, s->stream)) || (rc = upload(sl.d_len2, b->seg2_length, n * 4, s->stream)))) return rc;
+        if (b->mean_quality && (rc = upload(sl.d_mq, b->mean_quality, n * 4, s->stream))) return rc;
+        if (b->compression && (rc = upload(sl.d_comp, b->compression, n * 4, s->stream))) return rc;
+        bases = s->d_bases.as<uint32_t>();
+        nmask = b->nmask ? s->d_nmask.as<uint32_t>() : nullptr;
+        off1 = s->d_off1.as<uint64_t>(); sl.len1 = sl.d_len1.as<uint32_t>();
+        off2 = paired ? s->d_off2.as<uint64_t>() : nullptr; sl.len2 = paired ? sl.d_len2.as<uint32_t>() : nullptr;
+        sl.mq = b->mean_quality ? sl.d_mq.as<float>() : nullptr;
+        sl.comp = b->compression ? sl.d_comp.as<float>() : nullptr;
+        sl.h_len1.assign(b->seg1_length, b->seg1_length + n);
+        if (paired) sl.h_len2.assign(b->seg2_length, b->seg2_length + n); else sl.h_len2.clear();
+        if (b->mean_quality) sl.h_mq.assign(b->mean_quality, b->mean_quality + n); else sl.h_mq.clear();
+        if (b->compression) sl.h_comp.assign(b->compression, b->compression + n); else sl.h_comp.clear();
     } else {
-        s->bases = b->bases2; s->nmask = b->nmask; s->off1 = b->seg1_offset; s->len1 = b->seg1_length;
-        s->off2 = b->seg2_offset; s->len2 = b->seg2_length; s->mq = b->mean_quality; s->comp = b->compression;
+        bases = b->bases2; nmask = b->nmask; off1 = b->seg1_offset; sl.len1 = b->seg1_length;
+        off2 = b->seg2_offset; sl.len2 = b->seg2_length; sl.mq = b->mean_quality; sl.comp = b->compression;
     }
-    s->n_reads = n; s->n_bases = b->n_bases;
+    sl.n_reads = n;
     const bool prof = (s->cfg.flags & CHN_STREAM_PROFILE) != 0;
-    for (int i = 0; i < 4; ++i) s->ev_used[i] = false;
-    if (prof) HIPCHK(hipEventRecord(s->ev[6], s->stream));
+    for (int i = 0; i < 4; ++i) sl.ev_used[i] = false;
+    if (prof) HIPCHK(hipEventRecord(sl.ev[6], s->stream));
 
     // 1. length-class ordering
     HIPCHK(hipMemsetAsync(s->d_hist.p, 0, 256 * 4, s->stream));
-    hipLaunchKernelGGL(k_len_hist, dim3(std::min<uint64_t>(1024, (n + 255) / 256)), dim3(256), 0, s->stream, s->len1, s->len2, (uint32_t)n, s->d_hist.as<uint32_t>());
+    hipLaunchKernelGGL(k_len_hist, dim3(std::min<uint64_t>(1024, (n + 255) / 256)), dim3(256), 0, s->stream, sl.len1, sl.len2, (uint32_t)n, s->d_hist.as<uint32_t>());
     hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(64), 0, s->stream, s->d_hist.as<uint32_t>());
-    hipLaunchKernelGGL(k_len_scatter, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->len1, s->len2, (uint32_t)n, s->d_hist.as<uint32_t>(), s->d_order.as<uint32_t>());
+    hipLaunchKernelGGL(k_len_scatter, dim3((n + 255) / 256), dim3(256), 0, s->stream, sl.len1, sl.len2, (uint32_t)n, s->d_hist.as<uint32_t>(), s->d_order.as<uint32_t>());
     HIPCHK(hipGetLastError());
 
     // 2. minimise + probe
@@ -1122,28 +1145,28 @@ extern "C" int chn_batch_submit(chn_stream *s, const chn_batch *b) {
     a.shift = (uint32_t)d.hash_shift; a.h = d.hash_funs; a.k = d.kmer_size; a.wn = d.window_size - d.kmer_size + 1;
     a.n_reads = (uint32_t)n; a.nseg = paired ? 2 : 1; a.B = (uint32_t)d.bins; a.C = C;
     for (uint32_t bb = 0; bb < 8 && bb < d.bins; ++bb) a.b2c_packed |= (uint64_t)d.bin_to_category[bb] << (8 * bb);
-    a.bases = s->bases; a.nmask = s->nmask; a.off1 = s->off1; a.off2 = s->off2; a.len1 = s->len1; a.len2 = s->len2;
+    a.bases = bases; a.nmask = nmask; a.off1 = off1; a.off2 = off2; a.len1 = sl.len1; a.len2 = sl.len2;
     a.order = s->d_order.as<uint32_t>();
-    a.num_hashes = s->d_num_hashes.as<uint32_t>(); a.counts = s->d_counts.as<uint32_t>(); a.unique = s->d_unique.as<uint32_t>();
+    a.num_hashes = sl.d_num_hashes.as<uint32_t>(); a.counts = sl.d_counts.as<uint32_t>(); a.unique = sl.d_unique.as<uint32_t>();
     a.rows = s->d_rows.as<uint64_t>();
     const int mode = fused ? MODE_FUSED : MODE_ROWS;
     const size_t lds = k1_lds_bytes(a.wn, C, mode);
     if (lds > 160 * 1024) return fail(CHN_E_INVALID, "window too large for LDS");
-    if (prof) { HIPCHK(hipEventRecord(s->ev[0], s->stream)); }
+    if (prof) { HIPCHK(hipEventRecord(sl.ev[0], s->stream)); }
     hipError_t e = fused ? launch_k1_w<MODE_FUSED>(W, a, lds, s->stream) : launch_k1_w<MODE_ROWS>(W, a, lds, s->stream);
     if (e != hipSuccess) return fail(CHN_E_HIP, std::string("k_minimise_probe launch: ") + hipGetErrorString(e));
-    if (prof) { HIPCHK(hipEventRecord(s->ev[1], s->stream)); s->ev_used[0] = true; }
+    if (prof) { HIPCHK(hipEventRecord(sl.ev[1], s->stream)); sl.ev_used[0] = true; }
 
     // 3. counts from rows (general bin layouts)
     if (!fused) {
         K2Args k2;
         std::memset(&k2, 0, sizeof(k2));
-        k2.rows = s->d_rows.as<uint64_t>(); k2.off1 = s->off1; k2.num_hashes = s->d_num_hashes.as<uint32_t>();
-        k2.counts = s->d_counts.as<uint32_t>(); k2.unique = s->d_unique.as<uint32_t>();
+        k2.rows = s->d_rows.as<uint64_t>(); k2.off1 = off1; k2.num_hashes = sl.d_num_hashes.as<uint32_t>();
+        k2.counts = sl.d_counts.as<uint32_t>(); k2.unique = sl.d_unique.as<uint32_t>();
         k2.n_reads = (uint32_t)n; k2.B = (uint32_t)d.bins; k2.C = C; k2.W = W;
         std::memcpy(k2.b2c, d.bin_to_category, 256);
         const dim3 grid((uint32_t)((n + K2_WAVES - 1) / K2_WAVES)), block(WAVE * K2_WAVES);
-        if (prof) HIPCHK(hipEventRecord(s->ev[2], s->stream));
+        if (prof) HIPCHK(hipEventRecord(sl.ev[2], s->stream));
         switch (W) {
             case 1: hipLaunchKernelGGL(k_count_rows<1>, grid, block, 0, s->stream, k2); break;
             case 2: hipLaunchKernelGGL(k_count_rows<2>, grid, block, 0, s->stream, k2); break;
@@ -1151,29 +1174,34 @@ extern "C" int chn_batch_submit(chn_stream *s, const chn_batch *b) {
             default: hipLaunchKernelGGL(k_count_rows<4>, grid, block, 0, s->stream, k2); break;
         }
         HIPCHK(hipGetLastError());
-        if (prof) { HIPCHK(hipEventRecord(s->ev[3], s->stream)); s->ev_used[1] = true; }
+        if (prof) { HIPCHK(hipEventRecord(sl.ev[3], s->stream)); sl.ev_used[1] = true; }
     }
+    HIPCHK(hipEventRecord(sl.k2_done, s->stream));
 
-    // 4. model + call
+    // 4. model + call on the side stream (overlaps the next batch's minimise+probe)
+    HIPCHK(hipStreamWaitEvent(s->stream2, sl.k2_done, 0));
+    sl.model_ran = s->model.set;
     if (s->model.set) {
         K3Args k3 = s->k3;
-        k3.num_hashes = s->d_num_hashes.as<uint32_t>(); k3.counts = s->d_counts.as<uint32_t>(); k3.unique = s->d_unique.as<uint32_t>();
-        k3.len1 = s->len1; k3.len2 = s->len2; k3.mean_quality = s->mq; k3.compression = s->comp;
-        k3.prob = s->d_prob.as<double>(); k3.call = s->d_call.as<uint8_t>(); k3.conf = s->d_conf.as<uint8_t>(); k3.flags = s->d_flags.as<uint8_t>();
+        k3.num_hashes = sl.d_num_hashes.as<uint32_t>(); k3.counts = sl.d_counts.as<uint32_t>(); k3.unique = sl.d_unique.as<uint32_t>();
+        k3.len1 = sl.len1; k3.len2 = sl.len2; k3.mean_quality = sl.mq; k3.compression = sl.comp;
+        k3.prob = sl.d_prob.as<double>(); k3.call = sl.d_call.as<uint8_t>(); k3.conf = sl.d_conf.as<uint8_t>(); k3.flags = sl.d_flags.as<uint8_t>();
         k3.n_reads = (uint32_t)n;
-        if (prof) HIPCHK(hipEventRecord(s->ev[4], s->stream));
-        hipLaunchKernelGGL(k_model_call, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s->stream, k3);
+        if (prof) HIPCHK(hipEventRecord(sl.ev[4], s->stream2));
+        hipLaunchKernelGGL(k_model_call, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s->stream2, k3);
         HIPCHK(hipGetLastError());
-        if (prof) { HIPCHK(hipEventRecord(s->ev[5], s->stream)); s->ev_used[2] = true; }
+        if (prof) { HIPCHK(hipEventRecord(sl.ev[5], s->stream2)); sl.ev_used[2] = true; }
     }
-    if (prof) { HIPCHK(hipEventRecord(s->ev[7], s->stream)); s->ev_used[3] = true; }
+    if (prof) { HIPCHK(hipEventRecord(sl.ev[7], s->stream2)); sl.ev_used[3] = true; }
     // algorithmic byte count of this batch (outside the profiled chain)
-    HIPCHK(hipMemsetAsync(s->d_acc.p, 0, 16, s->stream));
-    hipLaunchKernelGGL(k_batch_bytes, dim3(std::min<uint64_t>(1024, (n + 255) / 256)), dim3(256), 0, s->stream, s->len1, s->len2,
-                       s->d_num_hashes.as<uint32_t>(), (uint32_t)n, (uint32_t)(d.hash_funs * W * 8), (uint32_t)(8 + 8 * C),
-                       s->d_acc.as<unsigned long long>());
+    HIPCHK(hipMemsetAsync(sl.d_acc.p, 0, 16, s->stream2));
+    hipLaunchKernelGGL(k_batch_bytes, dim3(std::min<uint64_t>(1024, (n + 255) / 256)), dim3(256), 0, s->stream2, sl.len1, sl.len2,
+                       sl.d_num_hashes.as<uint32_t>(), (uint32_t)n, (uint32_t)(d.hash_funs * W * 8), (uint32_t)(8 + 8 * C),
+                       sl.d_acc.as<unsigned long long>());
     HIPCHK(hipGetLastError());
-    s->submitted = true;
+    HIPCHK(hipEventRecord(sl.done, s->stream2));
+    s->head ^= 1;
+    s->inflight += 1;
     return CHN_OK;
 }
 
@@ -1181,50 +1209,52 @@ extern "C" int chn_stream_sync(chn_stream *s) {
     if (!s) return fail(CHN_E_INVALID, "null stream");
     HIPCHK(hipSetDevice(s->idx->d.device));
     HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream2));
     return CHN_OK;
 }
 
 extern "C" int chn_batch_wait(chn_stream *s, chn_result *r) {
     if (!s || !r || r->struct_size != sizeof(chn_result)) return fail(CHN_E_INVALID, "chn_batch_wait: bad argument");
-    if (!s->submitted) return fail(CHN_E_STATE, "no batch in flight");
+    if (s->inflight == 0) return fail(CHN_E_STATE, "no batch in flight");
     HIPCHK(hipSetDevice(s->idx->d.device));
-    HIPCHK(hipStreamSynchronize(s->stream));
-    s->submitted = false;
+    Slot &sl = s->slot[s->inflight == 2 ? s->head : (s->head ^ 1)];  // oldest batch in flight
+    HIPCHK(hipEventSynchronize(sl.done));
+    s->inflight -= 1;
     static const int evpair[4][2] = {{0, 1}, {2, 3}, {4, 5}, {6, 7}};
     for (int i = 0; i < 4; ++i)
-        if (s->ev_used[i]) {
+        if (sl.ev_used[i]) {
             float ms = 0;
-            HIPCHK(hipEventElapsedTime(&ms, s->ev[evpair[i][0]], s->ev[evpair[i][1]]));
+            HIPCHK(hipEventElapsedTime(&ms, sl.ev[evpair[i][0]], sl.ev[evpair[i][1]]));
             s->prof_ms[i] += ms; s->prof_n[i] += 1;
         }
     unsigned long long acc[2];
-    HIPCHK(hipMemcpy(acc, s->d_acc.p, 16, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(acc, sl.d_acc.p, 16, hipMemcpyDeviceToHost));
     s->last_bytes = acc[0]; s->last_min = acc[1];
-    const uint64_t n = s->n_reads, C = s->idx->d.num_categories;
-    if (r->on_device) {
-        r->num_hashes = s->d_num_hashes.as<uint32_t>(); r->counts = s->d_counts.as<uint32_t>(); r->unique_counts = s->d_unique.as<uint32_t>();
-        r->probabilities = s->d_prob.as<double>(); r->call = s->d_call.as<uint8_t>(); r->confidence = s->d_conf.as<uint8_t>();
-        r->flags = s->d_flags.as<uint8_t>();
+    const uint64_t n = sl.n_reads, C = s->idx->d.num_categories;
+    if (r->on_device) {  // valid until the second-next chn_batch_submit
+        r->num_hashes = sl.d_num_hashes.as<uint32_t>(); r->counts = sl.d_counts.as<uint32_t>(); r->unique_counts = sl.d_unique.as<uint32_t>();
+        r->probabilities = sl.d_prob.as<double>(); r->call = sl.d_call.as<uint8_t>(); r->confidence = sl.d_conf.as<uint8_t>();
+        r->flags = sl.d_flags.as<uint8_t>();
         return CHN_OK;
     }
-    if (r->num_hashes) HIPCHK(hipMemcpy(r->num_hashes, s->d_num_hashes.p, n * 4, hipMemcpyDeviceToHost));
-    if (r->counts) HIPCHK(hipMemcpy(r->counts, s->d_counts.p, n * C * 4, hipMemcpyDeviceToHost));
-    if (r->unique_counts) HIPCHK(hipMemcpy(r->unique_counts, s->d_unique.p, n * C * 4, hipMemcpyDeviceToHost));
-    if (s->model.set) {
-        if (r->probabilities) HIPCHK(hipMemcpy(r->probabilities, s->d_prob.p, n * C * 8, hipMemcpyDeviceToHost));
-        if (r->call) HIPCHK(hipMemcpy(r->call, s->d_call.p, n, hipMemcpyDeviceToHost));
-        if (r->confidence) HIPCHK(hipMemcpy(r->confidence, s->d_conf.p, n, hipMemcpyDeviceToHost));
+    if (r->num_hashes) HIPCHK(hipMemcpy(r->num_hashes, sl.d_num_hashes.p, n * 4, hipMemcpyDeviceToHost));
+    if (r->counts) HIPCHK(hipMemcpy(r->counts, sl.d_counts.p, n * C * 4, hipMemcpyDeviceToHost));
+    if (r->unique_counts) HIPCHK(hipMemcpy(r->unique_counts, sl.d_unique.p, n * C * 4, hipMemcpyDeviceToHost));
+    if (sl.model_ran) {
+        if (r->probabilities) HIPCHK(hipMemcpy(r->probabilities, sl.d_prob.p, n * C * 8, hipMemcpyDeviceToHost));
+        if (r->call) HIPCHK(hipMemcpy(r->call, sl.d_call.p, n, hipMemcpyDeviceToHost));
+        if (r->confidence) HIPCHK(hipMemcpy(r->confidence, sl.d_conf.p, n, hipMemcpyDeviceToHost));
         std::vector<uint8_t> flags(n);
-        HIPCHK(hipMemcpy(flags.data(), s->d_flags.p, n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(flags.data(), sl.d_flags.p, n, hipMemcpyDeviceToHost));
         if (r->flags) std::memcpy(r->flags, flags.data(), n);
         // borderline reads: re-evaluate with the host libm so that `call` never depends on a last-ulp exp() difference
-        if (s->host_batch && r->num_hashes && r->counts && r->unique_counts && r->call && r->confidence && r->probabilities) {
+        if (sl.host_batch && r->num_hashes && r->counts && r->unique_counts && r->call && r->confidence && r->probabilities) {
             std::vector<double> p(C);
             for (uint64_t i = 0; i < n; ++i)
                 if (flags[i] || r->num_hashes[i] == 0) {
-                    const uint32_t length = s->h_len1[i] + (s->h_len2.empty() ? 0u : s->h_len2[i]);
+                    const uint32_t length = sl.h_len1[i] + (sl.h_len2.empty() ? 0u : sl.h_len2[i]);
                     host_model_call(s->model, r->num_hashes[i], r->counts + i * C, r->unique_counts + i * C,
-                                    s->h_mq.empty() ? 0.0f : s->h_mq[i], s->h_comp.empty() ? 0.0f : s->h_comp[i], length, p.data(),
+                                    sl.h_mq.empty() ? 0.0f : sl.h_mq[i], sl.h_comp.empty() ? 0.0f : sl.h_comp[i], length, p.data(),
                                     &r->call[i], &r->confidence[i]);
                     for (uint64_t c = 0; c < C; ++c) r->probabilities[i * C + c] = p[c];
                 }
@@ -1239,32 +1269,33 @@ extern "C" int chn_classify_counts(chn_stream *s, uint64_t n, const uint32_t *nu
     if (!s || !num_hashes || !counts || !unique_counts || !lengths || !probabilities || !call || !confidence)
         return fail(CHN_E_INVALID, "chn_classify_counts: null argument");
     if (!s->model.set) return fail(CHN_E_STATE, "chn_classify_counts: no model set");
-    if (s->submitted) return fail(CHN_E_STATE, "chn_classify_counts: a batch is in flight");
+    if (s->inflight) return fail(CHN_E_STATE, "chn_classify_counts: a batch is in flight");
+    Slot &sl = s->slot[0];
     if (n == 0) return CHN_OK;
     if (n > s->cfg.max_reads) return fail(CHN_E_CAPACITY, "chn_classify_counts: more reads than the stream's max_reads");
     HIPCHK(hipSetDevice(s->idx->d.device));
     const uint64_t C = s->idx->d.num_categories;
     int rc;
-    if ((rc = upload(s->d_len1, lengths, n * 4, s->stream))) return rc;
-    if (mean_quality && (rc = upload(s->d_mq, mean_quality, n * 4, s->stream))) return rc;
-    if (compression && (rc = upload(s->d_comp, compression, n * 4, s->stream))) return rc;
-    HIPCHK(hipMemcpyAsync(s->d_num_hashes.p, num_hashes, n * 4, hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipMemcpyAsync(s->d_counts.p, counts, n * C * 4, hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipMemcpyAsync(s->d_unique.p, unique_counts, n * C * 4, hipMemcpyHostToDevice, s->stream));
+    if ((rc = upload(sl.d_len1, lengths, n * 4, s->stream))) return rc;
+    if (mean_quality && (rc = upload(sl.d_mq, mean_quality, n * 4, s->stream))) return rc;
+    if (compression && (rc = upload(sl.d_comp, compression, n * 4, s->stream))) return rc;
+    HIPCHK(hipMemcpyAsync(sl.d_num_hashes.p, num_hashes, n * 4, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(sl.d_counts.p, counts, n * C * 4, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(sl.d_unique.p, unique_counts, n * C * 4, hipMemcpyHostToDevice, s->stream));
     K3Args k3 = s->k3;
-    k3.num_hashes = s->d_num_hashes.as<uint32_t>(); k3.counts = s->d_counts.as<uint32_t>(); k3.unique = s->d_unique.as<uint32_t>();
-    k3.len1 = s->d_len1.as<uint32_t>(); k3.len2 = nullptr;
-    k3.mean_quality = mean_quality ? s->d_mq.as<float>() : nullptr; k3.compression = compression ? s->d_comp.as<float>() : nullptr;
-    k3.prob = s->d_prob.as<double>(); k3.call = s->d_call.as<uint8_t>(); k3.conf = s->d_conf.as<uint8_t>(); k3.flags = s->d_flags.as<uint8_t>();
+    k3.num_hashes = sl.d_num_hashes.as<uint32_t>(); k3.counts = sl.d_counts.as<uint32_t>(); k3.unique = sl.d_unique.as<uint32_t>();
+    k3.len1 = sl.d_len1.as<uint32_t>(); k3.len2 = nullptr;
+    k3.mean_quality = mean_quality ? sl.d_mq.as<float>() : nullptr; k3.compression = compression ? sl.d_comp.as<float>() : nullptr;
+    k3.prob = sl.d_prob.as<double>(); k3.call = sl.d_call.as<uint8_t>(); k3.conf = sl.d_conf.as<uint8_t>(); k3.flags = sl.d_flags.as<uint8_t>();
     k3.n_reads = (uint32_t)n;
     hipLaunchKernelGGL(k_model_call, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s->stream, k3);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s->stream));
-    HIPCHK(hipMemcpy(probabilities, s->d_prob.p, n * C * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(call, s->d_call.p, n, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(confidence, s->d_conf.p, n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(probabilities, sl.d_prob.p, n * C * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(call, sl.d_call.p, n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(confidence, sl.d_conf.p, n, hipMemcpyDeviceToHost));
     std::vector<uint8_t> flags(n);
-    HIPCHK(hipMemcpy(flags.data(), s->d_flags.p, n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(flags.data(), sl.d_flags.p, n, hipMemcpyDeviceToHost));
     std::vector<double> p(C);
     for (uint64_t i = 0; i < n; ++i)
         if (flags[i] || num_hashes[i] == 0) {  // borderline or NaN rows: host libm / host NaN sign

@@ -163,7 +163,10 @@ typedef struct chn_result {
     uint8_t *flags;            /* [n] */
 } chn_result;
 
-int chn_batch_submit(chn_stream *s, const chn_batch *b);   /* asynchronous on the stream */
+/* Up to TWO batches may be in flight per stream (submit, submit, wait, submit, wait, ...): batch i's model+call
+ * kernel runs on a side HIP stream and overlaps batch i+1's minimise+probe kernel.  chn_batch_wait returns the
+ * OLDEST batch in flight.  With on_device results the returned pointers stay valid until the second-next submit. */
+int chn_batch_submit(chn_stream *s, const chn_batch *b);   /* asynchronous */
 int chn_batch_wait(chn_stream *s, chn_result *r);          /* blocks; fills / points `r` */
 int chn_stream_sync(chn_stream *s);
 
