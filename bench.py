@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--read-len", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; nccl = RCCL (default). gloo only to rehearse N ranks on fewer GPUs")
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer entry (H2D of the packed batch + D2H of the results)")
     args = ap.parse_args()
 
@@ -58,10 +60,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
+    dev = local % ndev  # == local on a real N-GPU launch; wraps only in a gloo rehearsal on fewer GPUs
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
+    coll_dev = torch.device("cuda", dev) if args.backend == "nccl" else torch.device("cpu")
+    local = dev
     torch.cuda.set_device(local)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
@@ -120,7 +132,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -128,7 +140,7 @@ def main():
     call = api.device_download(local, res.call, n_reads, np.uint8)
     summary = shard.summary_counts(call, 2)
     if world > 1:
-        summary = shard.merge_summary(summary, dist, torch.device("cuda", local))
+        summary = shard.merge_summary(summary, dist, coll_dev)
 
     k1_ms, k1_n = stream.profile(0)
     k2_ms, k2_n = stream.profile(1)
