@@ -108,7 +108,10 @@ struct K1Args {
     const uint32_t *len1, *len2;
     const uint32_t *order;
     uint32_t *num_hashes, *counts, *unique;
-    uint64_t *rows;          // MODE_ROWS: row list of read r starts at row index off1[r]
+    uint64_t *rows;          // MODE_ROWS: per-wavefront row log, entry e of wavefront g at rows[(wave_base[g] + e) * W]
+    uint8_t *row_owner;      // MODE_ROWS: owner lane (read slot in the wavefront) of every log entry
+    const uint64_t *wave_base;
+    uint32_t *wave_count;    // MODE_ROWS: entries written by wavefront g
     const uint8_t *read_bin; // MODE_EMPLACE: target bin of "read" (genome chunk) r
 };
 
@@ -158,7 +161,6 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
 
     if (MODE == MODE_FUSED)
         for (uint32_t c = 0; c < a.C; ++c) { cnt[c * WAVE + lane] = 0; unq[c * WAVE + lane] = 0; }
-    if (MODE == MODE_ROWS) rbase[lane] = valid ? a.off1[r] : 0;
     if (MODE == MODE_EMPLACE) rbase[lane] = valid ? a.read_bin[r] : 0;
     __syncthreads();
 
@@ -171,6 +173,9 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
     uint32_t pend_meta = 0;
     bool pend_has = false;   // per lane
     bool pending = false;    // wave-uniform
+    uint32_t consumed = 0;   // MODE_ROWS: log entries written so far (wave-uniform)
+    uint32_t pend_n = 0;     // entries of the round in flight (wave-uniform)
+    const uint64_t wbase = (MODE == MODE_ROWS) ? a.wave_base[blockIdx.x] : 0;
 
     auto probe_consume = [&]() {
         if (MODE == MODE_EMPLACE) { pending = false; return; }
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
                     for (int w = 0; w < W; ++w) acc[w] &= pend[i][w];
                 }
         }
-        const uint32_t owner = pend_meta & 63u, idx = pend_meta >> 6;
+        const uint32_t owner = pend_meta & 63u;
         if (MODE == MODE_FUSED) {
             uint64_t m = pend_has ? (acc[0] & ((a.B >= 64) ? ~0ULL : ((1ULL << a.B) - 1))) : 0;
             const bool single = __popcll(m) == 1;
@@ -196,16 +201,19 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
                 atomicAdd(&cnt[c * WAVE + owner], 1u);
                 if (single) atomicAdd(&unq[c * WAVE + owner], 1u);
             }
-        } else {  // MODE_ROWS: append to the owner's row list (order inside a read is irrelevant to the counts)
+        } else {  // MODE_ROWS: append the round to the wavefront's row log -- 64 consecutive rows per round, fully coalesced
             if (pend_has) {
-                uint64_t *dst = a.rows + (rbase[owner] + idx) * W;
+                const uint64_t e = wbase + consumed + lane;
+                uint64_t *dst = a.rows + e * W;
                 if (W == 2) {
                     *reinterpret_cast<ulonglong2 *>(dst) = make_ulonglong2(acc[0], acc[1]);
                 } else {
 #pragma unroll
                     for (int w = 0; w < W; ++w) dst[w] = acc[w];
                 }
+                a.row_owner[e] = (uint8_t)owner;
             }
+            consumed += pend_n;
         }
         pending = false;
     };
@@ -227,6 +235,7 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
         } else {
             pend_has = has;
             pend_meta = meta;
+            pend_n = n_take;
             if (has) {
                 uint64_t rows_[5];
 #pragma unroll
@@ -368,6 +377,7 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
     if (qcount) { probe_issue(qcount); if (pending) probe_consume(); }
 
     __syncthreads();
+    if (MODE == MODE_ROWS && lane == 0) a.wave_count[blockIdx.x] = consumed;
     if (valid && MODE != MODE_EMPLACE) {
         a.num_hashes[r] = my_emitted;
         if (MODE == MODE_FUSED) {
@@ -380,88 +390,116 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_count_rows: ReadEntry::get_counts (include/read_entry.hpp:92-138) on the stored bit-rows
+// k_count_wavelog: ReadEntry::get_counts (include/read_entry.hpp:92-138) on the row log of one wavefront of
+// k_minimise_probe (64 reads).  One workgroup per log; all per-read state lives in LDS.
 // ------------------------------------------------------------------------------------------------
 struct K2Args {
     const uint64_t *rows;
-    const uint64_t *off1;
-    const uint32_t *num_hashes;
+    const uint8_t *row_owner;
+    const uint64_t *wave_base;
+    const uint32_t *wave_count;
+    const uint32_t *order;
     uint32_t *counts, *unique;
     uint32_t n_reads, B, C, W;
     uint8_t b2c[256];
 };
 
-#define K2_WAVES 4
+#define K2_THREADS 256
 template <int W>
-__global__ __launch_bounds__(WAVE *K2_WAVES) void k_count_rows(const K2Args a) {
-    __shared__ uint32_t s_tot[K2_WAVES][256];
-    __shared__ uint32_t s_unq[K2_WAVES][256];
-    __shared__ uint32_t s_chosen[K2_WAVES][256];
-    const uint32_t lane = lane_id(), wv = threadIdx.x / WAVE;
-    const uint32_t r = blockIdx.x * K2_WAVES + wv;
-    if (r >= a.n_reads) return;  // whole wavefront exits together; no block-wide barrier is used below
-    uint32_t *tot = s_tot[wv], *unq = s_unq[wv], *chosen = s_chosen[wv];
-    for (uint32_t b = lane; b < 256; b += WAVE) { tot[b] = 0; unq[b] = 0; chosen[b] = 255; }
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t M = a.num_hashes[r];
-    const uint64_t *rows = a.rows + a.off1[r] * W;
-    // pass A: total_bits_per_bin (:96-99)
-    for (uint32_t m = lane; m < M; m += WAVE) {
+__global__ __launch_bounds__(K2_THREADS) void k_count_wavelog(const K2Args a) {
+    extern __shared__ __align__(16) unsigned char smem2[];
+    const uint32_t B = a.B, C = a.C;
+    uint32_t *tot = reinterpret_cast<uint32_t *>(smem2);                 // [64][B] total_bits_per_bin (:96-99)
+    uint32_t *unq = tot + (size_t)WAVE * B;                              // [64][C]
+    uint64_t *cmask = reinterpret_cast<uint64_t *>(unq + (size_t)WAVE * C + ((WAVE * C) & 1u));  // [64][W] chosen-bin mask
+    uint8_t *chosen = reinterpret_cast<uint8_t *>(cmask + WAVE * W);     // [64][C]
+    __shared__ uint8_t s_b2c[256];
+    const uint32_t tid = threadIdx.x, g = blockIdx.x;
+    for (uint32_t i = tid; i < WAVE * B; i += K2_THREADS) tot[i] = 0;
+    for (uint32_t i = tid; i < WAVE * C; i += K2_THREADS) { unq[i] = 0; chosen[i] = 255; }
+    for (uint32_t i = tid; i < WAVE * W; i += K2_THREADS) cmask[i] = 0;
+    s_b2c[tid] = a.b2c[tid];
+    __syncthreads();
+    const uint32_t count = a.wave_count[g];
+    const uint64_t base = a.wave_base[g];
+    const uint64_t *rows = a.rows + base * W;
+    const uint8_t *own = a.row_owner + base;
+    const uint64_t lastmask = (B & 63u) ? ((1ULL << (B & 63u)) - 1) : ~0ULL;
+    // pass A: per-bin totals of each of the 64 reads
+    for (uint32_t e = tid; e < count; e += K2_THREADS) {
+        const uint32_t o = own[e];
 #pragma unroll
         for (int w = 0; w < W; ++w) {
-            uint64_t x = rows[(size_t)m * W + w];
-            if (w == W - 1 && (a.B & 63u)) x &= (1ULL << (a.B & 63u)) - 1;
+            uint64_t x = rows[(size_t)e * W + w];
+            if (w == W - 1) x &= lastmask;
             while (x) {
                 const uint32_t b = (uint32_t)__ffsll((long long)x) - 1;
                 x &= x - 1;
-                atomicAdd(&tot[w * 64 + b], 1u);
+                atomicAdd(&tot[o * B + w * 64 + b], 1u);
             }
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    // first bin with the strictly largest total per category (:102-115): key = total << 8 | (255 - bin)
-    uint64_t cmask[W];
-#pragma unroll
-    for (int w = 0; w < W; ++w) cmask[w] = 0;
-    for (uint32_t c = 0; c < a.C; ++c) {
-        uint64_t key = 0;
-        for (uint32_t b = lane; b < a.B; b += WAVE)
-            if (a.b2c[b] == c) {
-                const uint64_t kk = ((uint64_t)tot[b] << 8) | (255u - b);
-                key = kk > key ? kk : key;
-            }
-        // an existing bin always has key >= 1 (bin <= 254), so best == 0 means the category owns no bin: it keeps
-        // index 255 and count 0, as index_per_category does in the reference
-        const uint64_t best = wave_max_u64(key);
-        const bool cat_has_bin = best != 0;
-        if (cat_has_bin) {
-            const uint32_t bin = 255u - (uint32_t)(best & 0xffu);
-            if (lane == 0) {
-                chosen[c] = bin;
-                a.counts[(size_t)r * a.C + c] = (uint32_t)(best >> 8);
-            }
-#pragma unroll
-            for (int w = 0; w < W; ++w)
-                if ((bin >> 6) == (uint32_t)w) cmask[w] |= 1ULL << (bin & 63u);
-        } else if (lane == 0) {
-            a.counts[(size_t)r * a.C + c] = 0;
+    __syncthreads();
+    // first bin with the strictly largest total per category (:102-115), one thread per read
+    if (tid < WAVE) {
+        const uint32_t o = tid;
+        for (uint32_t b = 0; b < B; ++b) {
+            const uint32_t c = s_b2c[b];
+            const uint32_t cur = chosen[o * C + c];
+            if (cur == 255 || tot[o * B + b] > tot[o * B + cur]) chosen[o * C + c] = (uint8_t)b;
+        }
+        const uint32_t gi = g * WAVE + o;
+        const bool valid = gi < a.n_reads;
+        const uint32_t r = valid ? a.order[gi] : 0;
+        for (uint32_t c = 0; c < C; ++c) {
+            const uint32_t cb = chosen[o * C + c];
+            if (cb != 255) cmask[o * W + (cb >> 6)] |= 1ULL << (cb & 63u);
+            if (valid) a.counts[(size_t)r * C + c] = cb == 255 ? 0u : tot[o * B + cb];  // a category without bins keeps 0
         }
     }
+    __syncthreads();
     // pass B: a minimiser is a unique hit if exactly one category's chosen bin contains it (:121-136)
-    for (uint32_t m = lane; m < M; m += WAVE) {
+    for (uint32_t e = tid; e < count; e += K2_THREADS) {
+        const uint32_t o = own[e];
         uint32_t found = 0, fbin = 0;
 #pragma unroll
         for (int w = 0; w < W; ++w) {
-            const uint64_t x = rows[(size_t)m * W + w] & cmask[w];
+            const uint64_t x = rows[(size_t)e * W + w] & cmask[o * W + w];
             found += (uint32_t)__popcll(x);
             if (x) fbin = w * 64 + (uint32_t)__ffsll((long long)x) - 1;
         }
-        if (found == 1) atomicAdd(&unq[a.b2c[fbin]], 1u);
+        if (found == 1) atomicAdd(&unq[o * C + s_b2c[fbin]], 1u);
     }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    for (uint32_t c = lane; c < a.C; c += WAVE) a.unique[(size_t)r * a.C + c] = unq[c];
+    __syncthreads();
+    for (uint32_t i = tid; i < WAVE * C; i += K2_THREADS) {
+        const uint32_t o = i / C, c = i % C, gi = g * WAVE + o;
+        if (gi < a.n_reads) a.unique[(size_t)a.order[gi] * C + c] = unq[i];
+    }
+}
+static size_t k2_lds_bytes(uint32_t B, uint32_t C, uint32_t W) {
+    return (size_t)WAVE * B * 4 + ((size_t)WAVE * C + ((WAVE * C) & 1u)) * 4 + (size_t)WAVE * W * 8 + (size_t)WAVE * C + 16;
+}
+
+// capacity of a wavefront's row log = total bases of its 64 reads (at most one emission per base), then an exclusive scan
+__global__ void k_wave_caps(const uint32_t *order, const uint32_t *len1, const uint32_t *len2, uint32_t n, uint64_t *caps) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t v = 0;
+    if (i < n) { const uint32_t r = order[i]; v = len1[r] + (len2 ? len2[r] : 0u); }
+    uint64_t sum = v;
+    for (int o = 32; o > 0; o >>= 1) sum += (uint64_t)__shfl_xor((long long)sum, o);
+    if (lane_id() == 0 && i < n) caps[i / WAVE] = sum;
+}
+__global__ __launch_bounds__(1024) void k_scan_u64(uint64_t *v, uint32_t n) {  // in place exclusive scan, single workgroup
+    __shared__ uint64_t part[1024];
+    const uint32_t per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = min(n, lo + per);
+    uint64_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += v[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint64_t run = 0; for (int i = 0; i < 1024; ++i) { const uint64_t t = part[i]; part[i] = run; run += t; } }
+    __syncthreads();
+    uint64_t run = part[threadIdx.x];
+    for (uint32_t i = lo; i < hi; ++i) { const uint64_t t = v[i]; v[i] = run; run += t; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -777,7 +815,7 @@ struct chn_stream {
     hipStream_t stream2 = nullptr;  // model+call
     // staging of host batches (large arrays; reused by the next batch in stream order)
     DevBuf d_bases, d_nmask, d_off1, d_off2;
-    DevBuf d_order, d_hist, d_rows, d_model;
+    DevBuf d_order, d_hist, d_rows, d_rowown, d_wbase, d_wcount, d_model;
     Slot slot[2];
     int head = 0;      // slot of the next submit
     int inflight = 0;  // batches submitted and not yet waited for (FIFO)
@@ -970,7 +1008,9 @@ extern "C" int chn_stream_create(chn_index *idx, const chn_stream_cfg *cfg, chn_
     if ((rc = s->d_order.ensure(n * 4)) || (rc = s->d_hist.ensure(256 * 4))) { chn_stream_destroy(s); return rc; }
     const bool fused = idx->single_bin_categories && C <= 8 && idx->d.bin_words == 1;
     if (!fused) {
-        if ((rc = s->d_rows.ensure(cfg->max_bases * idx->d.bin_words * 8))) { chn_stream_destroy(s); return rc; }
+        const uint64_t nw = (n + WAVE - 1) / WAVE;
+        if ((rc = s->d_rows.ensure(cfg->max_bases * idx->d.bin_words * 8)) || (rc = s->d_rowown.ensure(cfg->max_bases)) ||
+            (rc = s->d_wbase.ensure(nw * 8)) || (rc = s->d_wcount.ensure(nw * 4))) { chn_stream_destroy(s); return rc; }
     }
     *out = s;
     return CHN_OK;
@@ -990,7 +1030,7 @@ extern "C" int chn_stream_destroy(chn_stream *s) {
                           &sl.d_len1, &sl.d_len2, &sl.d_mq, &sl.d_comp};
         for (DevBuf *b : bufs) b->release();
     }
-    DevBuf *bufs[] = {&s->d_bases, &s->d_nmask, &s->d_off1, &s->d_off2, &s->d_order, &s->d_hist, &s->d_rows, &s->d_model};
+    DevBuf *bufs[] = {&s->d_bases, &s->d_nmask, &s->d_off1, &s->d_off2, &s->d_order, &s->d_hist, &s->d_rows, &s->d_rowown, &s->d_wbase, &s->d_wcount, &s->d_model};
     for (DevBuf *b : bufs) b->release();
     delete s;
     return CHN_OK;
@@ -1048,6 +1088,10 @@ extern "C" int chn_model_set(chn_stream *s, const chn_model *m) {
 template <int W, int MODE>
 static hipError_t launch_k1(const K1Args &a, size_t lds, hipStream_t st) {
     const uint32_t blocks = (a.n_reads + WAVE - 1) / WAVE;
+    if (lds > 48 * 1024) {  // long windows: opt in to large dynamic LDS
+        hipError_t e = hipFuncSetAttribute((const void *)k_minimise_probe<W, MODE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     if (a.wn == 23)  // w=41, k=19: the defaults every real Charon index uses (include/index_arguments.hpp:16-17)
         hipLaunchKernelGGL((k_minimise_probe<W, MODE, 23>), dim3(blocks), dim3(WAVE), lds, st, a);
     else
@@ -1102,7 +1146,6 @@ extern "C" int chn_batch_submit(chn_stream *s, const chn_batch *b) {
             if (paired) {
                 const uint64_t o2 = b->seg2_offset[i], l2 = b->seg2_length[i];
                 if ((o2 & 63) || o2 + l2 > b->n_bases) return fail(CHN_E_INVALID, "segment 2 of read " + std::to_string(i) + " is misaligned or out of range");
-                if (!fused && o2 != ((o1 + l1 + 63) & ~63ULL)) return fail(CHN_E_INVALID, "paired batches need mate 2 stored directly after mate 1 (64-base padded)");
             }
         }
         int rc;
@@ -1148,7 +1191,15 @@ extern "C" int chn_batch_submit(chn_stream *s, const chn_batch *b) {
     a.bases = bases; a.nmask = nmask; a.off1 = off1; a.off2 = off2; a.len1 = sl.len1; a.len2 = sl.len2;
     a.order = s->d_order.as<uint32_t>();
     a.num_hashes = sl.d_num_hashes.as<uint32_t>(); a.counts = sl.d_counts.as<uint32_t>(); a.unique = sl.d_unique.as<uint32_t>();
-    a.rows = s->d_rows.as<uint64_t>();
+    a.rows = s->d_rows.as<uint64_t>(); a.row_owner = s->d_rowown.as<uint8_t>();
+    a.wave_base = s->d_wbase.as<uint64_t>(); a.wave_count = s->d_wcount.as<uint32_t>();
+    const uint32_t n_waves = (uint32_t)((n + WAVE - 1) / WAVE);
+    if (!fused) {
+        hipLaunchKernelGGL(k_wave_caps, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s->stream, s->d_order.as<uint32_t>(), sl.len1, sl.len2,
+                           (uint32_t)n, s->d_wbase.as<uint64_t>());
+        hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s->stream, s->d_wbase.as<uint64_t>(), n_waves);
+        HIPCHK(hipGetLastError());
+    }
     const int mode = fused ? MODE_FUSED : MODE_ROWS;
     const size_t lds = k1_lds_bytes(a.wn, C, mode);
     if (lds > 160 * 1024) return fail(CHN_E_INVALID, "window too large for LDS");
@@ -1161,17 +1212,24 @@ extern "C" int chn_batch_submit(chn_stream *s, const chn_batch *b) {
     if (!fused) {
         K2Args k2;
         std::memset(&k2, 0, sizeof(k2));
-        k2.rows = s->d_rows.as<uint64_t>(); k2.off1 = off1; k2.num_hashes = sl.d_num_hashes.as<uint32_t>();
+        k2.rows = s->d_rows.as<uint64_t>(); k2.row_owner = s->d_rowown.as<uint8_t>();
+        k2.wave_base = s->d_wbase.as<uint64_t>(); k2.wave_count = s->d_wcount.as<uint32_t>(); k2.order = s->d_order.as<uint32_t>();
         k2.counts = sl.d_counts.as<uint32_t>(); k2.unique = sl.d_unique.as<uint32_t>();
         k2.n_reads = (uint32_t)n; k2.B = (uint32_t)d.bins; k2.C = C; k2.W = W;
         std::memcpy(k2.b2c, d.bin_to_category, 256);
-        const dim3 grid((uint32_t)((n + K2_WAVES - 1) / K2_WAVES)), block(WAVE * K2_WAVES);
+        const dim3 grid(n_waves), block(K2_THREADS);
+        const size_t lds2 = k2_lds_bytes((uint32_t)d.bins, C, W);
+        if (lds2 > 150 * 1024) return fail(CHN_E_INVALID, "bins x categories too large for the count kernel's LDS");
+        if (lds2 > 48 * 1024) {  // opt in to large dynamic LDS
+            const void *fn = W == 1 ? (const void *)k_count_wavelog<1> : W == 2 ? (const void *)k_count_wavelog<2> : W == 3 ? (const void *)k_count_wavelog<3> : (const void *)k_count_wavelog<4>;
+            HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        }
         if (prof) HIPCHK(hipEventRecord(sl.ev[2], s->stream));
         switch (W) {
-            case 1: hipLaunchKernelGGL(k_count_rows<1>, grid, block, 0, s->stream, k2); break;
-            case 2: hipLaunchKernelGGL(k_count_rows<2>, grid, block, 0, s->stream, k2); break;
-            case 3: hipLaunchKernelGGL(k_count_rows<3>, grid, block, 0, s->stream, k2); break;
-            default: hipLaunchKernelGGL(k_count_rows<4>, grid, block, 0, s->stream, k2); break;
+            case 1: hipLaunchKernelGGL(k_count_wavelog<1>, grid, block, lds2, s->stream, k2); break;
+            case 2: hipLaunchKernelGGL(k_count_wavelog<2>, grid, block, lds2, s->stream, k2); break;
+            case 3: hipLaunchKernelGGL(k_count_wavelog<3>, grid, block, lds2, s->stream, k2); break;
+            default: hipLaunchKernelGGL(k_count_wavelog<4>, grid, block, lds2, s->stream, k2); break;
         }
         HIPCHK(hipGetLastError());
         if (prof) { HIPCHK(hipEventRecord(sl.ev[3], s->stream)); sl.ev_used[1] = true; }
