@@ -53,6 +53,10 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; nccl = RCCL (default). gloo only to rehearse N ranks on fewer GPUs")
+    ap.add_argument("--shard", default="reads", choices=["reads", "rows"],
+                    help="reads (default): full index replica per rank, reads sharded, no data-path collective; "
+                         "rows: index row-range sharded over ranks, every rank minimises the same batch, one RCCL sum "
+                         "all-reduce of the probe words per batch (for indexes that do not fit one GPU)")
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer entry (H2D of the packed batch + D2H of the results)")
     args = ap.parse_args()
 
@@ -90,13 +94,18 @@ def main():
     categories = ["human", "microbial"]
 
     t_setup = time.time()
-    desc = api.make_desc(B, S, b2c, 2, 0, device=local)
+    rows_mode = args.shard == "rows"
+    if rows_mode:
+        rlo, rhi = shard.shard_range(S, rank, world)
+        desc = api.make_desc(B, S, b2c, 2, 0, device=local, row_begin=rlo, row_end=rhi)
+    else:
+        desc = api.make_desc(B, S, b2c, 2, 0, device=local)
     index = api.Index(desc)
     index.synth_fill(43, wl["fill"])
     genomes = api.synth_genomes(local, 43, B, wl["genome_len"])
     index.synth_plant(genomes, B, wl["genome_len"], list(range(B)))
     # weak scaling: rank r classifies global reads [r*n, (r+1)*n) of one seeded read set (charon_amd/shard.py)
-    lo, hi = shard.shard_range(n_reads * world, rank, world)
+    lo, hi = (0, n_reads) if rows_mode else shard.shard_range(n_reads * world, rank, world)
     reads = api.synth_reads(local, 42, genomes, B, wl["genome_len"], hi - lo, L, L, 0.05, 0.10, 40.0, first_read_id=lo)
     stream = api.Stream(index, n_reads, reads.n_bases, profile=True)
     stream.set_model(api.default_model(2, 0))
@@ -106,7 +115,31 @@ def main():
         stream.submit_device(n_reads, reads.n_bases, reads.bases2, reads.seg1_offset, reads.seg1_length, reads.mean_quality,
                              reads.compression)
 
+    def run_steps_rows(k):
+        """row-sharded chain: minimise (all ranks, same batch) -> probe own rows -> ONE sum all-reduce -> AND/count/call"""
+        res = None
+        for _ in range(k):
+            e = stream.shard_minimise_device(n_reads, reads.n_bases, reads.bases2, reads.seg1_offset, reads.seg1_length,
+                                             reads.mean_quality, reads.compression)
+            nwords = e * 3 * ((B + 63) // 64)
+            partial = torch.empty(max(nwords, 1), dtype=torch.int64, device=torch.device("cuda", local))
+            stream.shard_probe(index, partial.data_ptr(), nwords)
+            if world > 1:
+                if args.backend == "nccl":
+                    dist.all_reduce(partial, op=dist.ReduceOp.SUM)
+                else:  # gloo rehearsal: through host memory
+                    hp = partial.cpu()
+                    dist.all_reduce(hp, op=dist.ReduceOp.SUM)
+                    partial.copy_(hp)
+                torch.cuda.synchronize()
+            stream.shard_finish(partial.data_ptr())
+            res = stream.wait_device()
+            del partial
+        return res
+
     def run_steps(k):
+        if rows_mode:
+            return run_steps_rows(k)
         """k whole passes of the chain; two batches in flight so that step i's model+call kernel (side stream) overlaps
         step i+1's minimise+probe kernel.  Every step's work starts and ends inside the caller's timed region."""
         res = None
@@ -139,7 +172,7 @@ def main():
     # summary counters (ResultSummary, include/result.hpp:18-25): the one collective of the read-sharded mode
     call = api.device_download(local, res.call, n_reads, np.uint8)
     summary = shard.summary_counts(call, 2)
-    if world > 1:
+    if world > 1 and not rows_mode:  # in rows mode every rank already holds the calls of the whole batch
         summary = shard.merge_summary(summary, dist, coll_dev)
 
     k1_ms, k1_n = stream.profile(0)
@@ -171,19 +204,20 @@ def main():
         achieved = alg_bytes / (k1_avg * 1e-3) / 1e9 if k1_avg > 0 else 0.0
         out = {
             "metric": "classified reads/sec + achieved HBM GB/s vs roofline, 5 kb reads, 39 GB index",
-            "value": world * args.steps * n_reads / elapsed,
+            "value": (1 if rows_mode else world) * args.steps * n_reads / elapsed,
             "unit": "reads/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if rows_mode else "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": wl["desc"], "reads_per_step_per_gpu": n_reads, "read_len": L, "index_bytes": S * ((B + 63) // 64) * 8,
-                       "sharding": "reads sharded over ranks, full index replica per GPU, no data-path collective",
+                       "sharding": ("index rows sharded over ranks, same batch on every rank, one sum all-reduce of probe words per batch" if rows_mode else
+                                    "reads sharded over ranks, full index replica per GPU, no data-path collective"),
                        "mean_minimisers_per_read": total_min / n_reads, "borderline_reads": int(flags.sum()),
                        "summary_counts": {"human": int(summary[0]), "microbial": int(summary[1]), "unclassified": int(summary[2])},
                        "setup_seconds": round(setup_s, 1), "pcie_inclusive_reads_per_s": pcie_rate},
@@ -193,7 +227,7 @@ def main():
                          "other_kernels_avg_ms": {"k_count_rows": k2_ms / max(k2_n, 1), "k_model_call": k3_ms / max(k3_n, 1),
                                                   "whole_chain": chain_ms / max(chain_n, 1)}},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not rows_mode:
             out["cpu_baseline"] = cpu_baseline(api, index, reads, res, n_reads, args, local, categories, b2c)
     stream.destroy()
     index.destroy()

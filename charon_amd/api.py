@@ -63,7 +63,8 @@ EXPORTS = ["chn_index_create", "chn_index_upload_rows", "chn_index_device_words"
            "chn_index_get_desc", "chn_index_destroy", "chn_model_default", "chn_stream_create", "chn_stream_destroy",
            "chn_model_set", "chn_batch_submit", "chn_batch_wait", "chn_stream_sync", "chn_classify_counts", "chn_stream_profile",
            "chn_stream_last_batch_bytes", "chn_synth_genomes", "chn_synth_fill_index", "chn_synth_plant", "chn_synth_reads",
-           "chn_device_free", "chn_device_download", "chn_last_error", "chn_version"]
+           "chn_device_free", "chn_device_download", "chn_device_malloc", "chn_device_upload", "chn_shard_minimise",
+           "chn_shard_probe", "chn_shard_finish", "chn_last_error", "chn_version"]
 
 _L.chn_last_error.restype = C.c_char_p
 _L.chn_version.restype = C.c_char_p
@@ -89,6 +90,11 @@ _L.chn_synth_plant.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C
 _L.chn_synth_reads.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                C.c_double, C.c_double, C.c_float, C.POINTER(SynthReadsOut)]
 _L.chn_device_free.argtypes = [C.c_int, C.c_void_p]
+_L.chn_device_malloc.argtypes = [C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]
+_L.chn_device_upload.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
+_L.chn_shard_minimise.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(C.c_uint64)]
+_L.chn_shard_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+_L.chn_shard_finish.argtypes = [C.c_void_p, C.c_void_p]
 _L.chn_device_download.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
 
 
@@ -192,6 +198,11 @@ class Stream:
 
     def submit_host(self, packed, mean_quality=None, compression=None):
         """packed: dict from charon_amd.pack.pack_reads"""
+        b, keep, n = self._host_batch(packed, mean_quality, compression)
+        _chk(_L.chn_batch_submit(self.h, C.byref(b)))
+        self._fifo.append((n, keep))
+
+    def _host_batch(self, packed, mean_quality, compression):
         n = len(packed["seg1_length"])
         b = Batch()
         b.struct_size, b.on_device, b.n_reads, b.n_bases = C.sizeof(Batch), 0, n, packed["n_bases"]
@@ -212,8 +223,32 @@ class Stream:
         b.seg2_length = ptr(packed.get("seg2_length"), np.uint32)
         b.mean_quality = ptr(mean_quality, np.float32)
         b.compression = ptr(compression, np.float32)
-        _chk(_L.chn_batch_submit(self.h, C.byref(b)))
-        self._fifo.append((n, keep))
+        return b, keep, n
+
+    # ---- row-sharded mode (see include/charon_hip.h) ----
+    def shard_minimise_host(self, packed):
+        b, keep, n = self._host_batch(packed, None, None)
+        e = C.c_uint64()
+        _chk(_L.chn_shard_minimise(self.h, C.byref(b), C.byref(e)))
+        self._shard = (n, keep)
+        return e.value
+
+    def shard_minimise_device(self, n_reads, n_bases, bases2, seg1_offset, seg1_length, mean_quality=None, compression=None):
+        b = Batch()
+        b.struct_size, b.on_device, b.n_reads, b.n_bases = C.sizeof(Batch), 1, n_reads, n_bases
+        b.bases2, b.seg1_offset, b.seg1_length, b.mean_quality, b.compression = bases2, seg1_offset, seg1_length, mean_quality, compression
+        e = C.c_uint64()
+        _chk(_L.chn_shard_minimise(self.h, C.byref(b), C.byref(e)))
+        self._shard = (n_reads, None)
+        return e.value
+
+    def shard_probe(self, shard_index, dev_partial, capacity_words):
+        _chk(_L.chn_shard_probe(self.h, shard_index.h, dev_partial, capacity_words))
+
+    def shard_finish(self, dev_partial):
+        _chk(_L.chn_shard_finish(self.h, dev_partial))
+        self._fifo.append(self._shard)
+        self._shard = None
 
     def submit_device(self, n_reads, n_bases, bases2, seg1_offset, seg1_length, mean_quality=None, compression=None,
                       nmask=None, seg2_offset=None, seg2_length=None):
@@ -282,6 +317,17 @@ def synth_reads(device, seed, dev_genomes, n_genomes, genome_len, n_reads, len_m
     _chk(_L.chn_synth_reads(device, seed, dev_genomes, n_genomes, genome_len, first_read_id, n_reads, len_min, len_max, sub_rate,
                             random_fraction, mean_quality, C.byref(out)))
     return out
+
+
+def device_malloc(device, nbytes):
+    p = C.c_void_p()
+    _chk(_L.chn_device_malloc(device, nbytes, C.byref(p)))
+    return p.value
+
+
+def device_upload(device, ptr, arr):
+    arr = np.ascontiguousarray(arr)
+    _chk(_L.chn_device_upload(device, ptr, arr.ctypes.data, arr.nbytes))
 
 
 def device_free(device, ptr):

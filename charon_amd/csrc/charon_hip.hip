@@ -95,12 +95,12 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 // ------------------------------------------------------------------------------------------------
 // k_minimise_probe
 // ------------------------------------------------------------------------------------------------
-enum { MODE_FUSED = 0, MODE_ROWS = 1, MODE_EMPLACE = 2 };
+enum { MODE_FUSED = 0, MODE_ROWS = 1, MODE_EMPLACE = 2, MODE_LIST = 3 };  // LIST: log the minimiser values themselves (row-sharded mode)
 
 struct K1Args {
     const uint64_t *words;   // IBF shard, word (row - row_begin) * W + b
     uint64_t *words_rw;      // MODE_EMPLACE
-    uint64_t S, row_begin, seed, powk1;
+    uint64_t S, row_begin, row_end, seed, powk1;
     uint32_t shift, h, k, wn, n_reads, nseg, B, C;
     uint64_t b2c_packed;     // MODE_FUSED: category of bin b in byte b
     const uint32_t *bases, *nmask;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
     bool pending = false;    // wave-uniform
     uint32_t consumed = 0;   // MODE_ROWS: log entries written so far (wave-uniform)
     uint32_t pend_n = 0;     // entries of the round in flight (wave-uniform)
-    const uint64_t wbase = (MODE == MODE_ROWS) ? a.wave_base[blockIdx.x] : 0;
+    const uint64_t wbase = (MODE == MODE_ROWS || MODE == MODE_LIST) ? a.wave_base[blockIdx.x] : 0;
 
     auto probe_consume = [&]() {
         if (MODE == MODE_EMPLACE) { pending = false; return; }
@@ -183,12 +183,16 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
 #pragma unroll
         for (int w = 0; w < W; ++w) acc[w] = ~0ULL;
         if (pend_has) {
+            if (MODE == MODE_LIST) {
+                acc[0] = pend[0][0];
+            } else {
 #pragma unroll
-            for (uint32_t i = 0; i < 5; ++i)
-                if (i < a.h) {
+                for (uint32_t i = 0; i < 5; ++i)
+                    if (i < a.h) {
 #pragma unroll
-                    for (int w = 0; w < W; ++w) acc[w] &= pend[i][w];
-                }
+                        for (int w = 0; w < W; ++w) acc[w] &= pend[i][w];
+                    }
+            }
         }
         const uint32_t owner = pend_meta & 63u;
         if (MODE == MODE_FUSED) {
@@ -229,14 +233,17 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
                 const uint32_t bin = (uint32_t)rbase[meta & 63u];
                 for (uint32_t i = 0; i < a.h; ++i) {
                     uint64_t row = hash_and_fit_row(val, c_ibf_seeds[i], a.S, a.shift);
-                    atomicOr((unsigned long long *)&a.words_rw[(row - a.row_begin) * W + (bin >> 6)], 1ULL << (bin & 63));
+                    if (row >= a.row_begin && row < a.row_end)
+                        atomicOr((unsigned long long *)&a.words_rw[(row - a.row_begin) * W + (bin >> 6)], 1ULL << (bin & 63));
                 }
             }
         } else {
             pend_has = has;
             pend_meta = meta;
             pend_n = n_take;
-            if (has) {
+            if (MODE == MODE_LIST) {
+                if (has) pend[0][0] = val;
+            } else if (has) {
                 uint64_t rows_[5];
 #pragma unroll
                 for (uint32_t i = 0; i < 5; ++i)
@@ -377,7 +384,7 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
     if (qcount) { probe_issue(qcount); if (pending) probe_consume(); }
 
     __syncthreads();
-    if (MODE == MODE_ROWS && lane == 0) a.wave_count[blockIdx.x] = consumed;
+    if ((MODE == MODE_ROWS || MODE == MODE_LIST) && lane == 0) a.wave_count[blockIdx.x] = consumed;
     if (valid && MODE != MODE_EMPLACE) {
         a.num_hashes[r] = my_emitted;
         if (MODE == MODE_FUSED) {
@@ -503,6 +510,58 @@ __global__ __launch_bounds__(1024) void k_scan_u64(uint64_t *v, uint32_t n) {  /
 }
 
 // ------------------------------------------------------------------------------------------------
+// row-sharded ("hash-bin" sharded) probing: every rank holds rows [row_begin, row_end) of the IBF.  A probe word is
+// written by exactly one rank (all others write 0), so one sum all-reduce of the partial buffer reconstructs it
+// exactly; the AND over the h hash functions happens afterwards.
+// ------------------------------------------------------------------------------------------------
+struct ShardArgs {
+    const uint64_t *list;        // minimiser values, wavefront log layout
+    const uint64_t *wave_base;   // start of wavefront g's region in `list` / `rows`
+    const uint64_t *cbase;       // start of wavefront g's entries in the COMPACT partial buffer
+    const uint32_t *wave_count;
+    const uint64_t *words;
+    uint64_t S, row_begin, row_end;
+    uint32_t shift, h, W;
+    uint64_t *partial;           // [entry][h][W]
+    uint64_t *rows;              // wavefront log of ANDed rows (k_and_partial)
+};
+template <int W>
+__global__ __launch_bounds__(256) void k_probe_partial(const ShardArgs a) {
+    const uint32_t g = blockIdx.x, count = a.wave_count[g];
+    const uint64_t *list = a.list + a.wave_base[g];
+    uint64_t *out = a.partial + a.cbase[g] * a.h * W;
+    for (uint32_t e = threadIdx.x; e < count; e += blockDim.x) {
+        const uint64_t val = list[e];
+        for (uint32_t i = 0; i < a.h; ++i) {
+            const uint64_t row = hash_and_fit_row(val, c_ibf_seeds[i], a.S, a.shift);
+            const bool mine = row >= a.row_begin && row < a.row_end;
+            const uint64_t *p = a.words + (mine ? (row - a.row_begin) * W : 0);
+#pragma unroll
+            for (int w = 0; w < W; ++w) out[((size_t)e * a.h + i) * W + w] = mine ? __builtin_nontemporal_load(p + w) : 0ULL;
+        }
+    }
+}
+template <int W>
+__global__ __launch_bounds__(256) void k_and_partial(const ShardArgs a) {
+    const uint32_t g = blockIdx.x, count = a.wave_count[g];
+    const uint64_t *in = a.partial + a.cbase[g] * a.h * W;
+    uint64_t *rows = a.rows + a.wave_base[g] * W;
+    for (uint32_t e = threadIdx.x; e < count; e += blockDim.x) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            uint64_t acc = ~0ULL;
+            for (uint32_t i = 0; i < a.h; ++i) acc &= in[((size_t)e * a.h + i) * W + w];
+            rows[(size_t)e * W + w] = acc;
+        }
+    }
+}
+__global__ void k_counts_to_u64(const uint32_t *c, uint32_t n, uint64_t *out /* n + 1 */) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = c[i];
+    else if (i == n) out[i] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_model_call: apply_model + call_host / call_category
 // ------------------------------------------------------------------------------------------------
 struct K3Args {
@@ -619,34 +678,49 @@ __device__ __forceinline__ uint32_t len_bucket(uint32_t len) {
     const uint32_t e = 31u - (uint32_t)__clz((int)len);
     return (e - 2) * 8 + ((len >> (e - 3)) & 7u);  // 8..247
 }
-__global__ void k_len_hist(const uint32_t *len1, const uint32_t *len2, uint32_t n, uint32_t *hist) {
+// Stable (deterministic) counting sort: the read -> wavefront assignment must be identical on every rank of the
+// row-sharded mode, and reproducible run to run.  LEN_BLOCKS workgroups each own a contiguous chunk of reads.
+#define LEN_BLOCKS 256
+__global__ __launch_bounds__(256) void k_len_hist(const uint32_t *len1, const uint32_t *len2, uint32_t n, uint32_t *blockhist /* [LEN_BLOCKS][256] */) {
     __shared__ uint32_t sh[256];
     sh[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        atomicAdd(&sh[len_bucket(len1[i] + (len2 ? len2[i] : 0u))], 1u);
+    const uint32_t chunk = (n + LEN_BLOCKS - 1) / LEN_BLOCKS, lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&sh[len_bucket(len1[i] + (len2 ? len2[i] : 0u))], 1u);
     __syncthreads();
-    if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+    blockhist[blockIdx.x * 256 + threadIdx.x] = sh[threadIdx.x];
 }
-__global__ void k_len_scan(uint32_t *hist /* in: counts, out: start cursor, longest bucket first */) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        uint32_t run = 0;
-        for (int b = 255; b >= 0; --b) { const uint32_t c = hist[b]; hist[b] = run; run += c; }
+__global__ __launch_bounds__(256) void k_len_scan(uint32_t *blockhist /* in: counts; out: start position of (block, bucket) */) {
+    __shared__ uint32_t tot[256], start[256];
+    const uint32_t b = threadIdx.x;
+    uint32_t t = 0;
+    for (uint32_t k = 0; k < LEN_BLOCKS; ++k) t += blockhist[k * 256 + b];
+    tot[b] = t;
+    __syncthreads();
+    if (b == 0) { uint32_t run = 0; for (int x = 255; x >= 0; --x) { start[x] = run; run += tot[x]; } }  // longest bucket first
+    __syncthreads();
+    uint32_t run = start[b];
+    for (uint32_t k = 0; k < LEN_BLOCKS; ++k) { const uint32_t c = blockhist[k * 256 + b]; blockhist[k * 256 + b] = run; run += c; }
+}
+__global__ __launch_bounds__(256) void k_len_scatter(const uint32_t *len1, const uint32_t *len2, uint32_t n, const uint32_t *blockstart, uint32_t *order) {
+    __shared__ uint32_t cursor[256];
+    __shared__ uint16_t tile[256];
+    cursor[threadIdx.x] = blockstart[blockIdx.x * 256 + threadIdx.x];
+    const uint32_t chunk = (n + LEN_BLOCKS - 1) / LEN_BLOCKS, lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+    for (uint32_t base = lo; base < hi; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t bk = i < hi ? len_bucket(len1[i] + (len2 ? len2[i] : 0u)) : 0xffffu;
+        __syncthreads();
+        tile[threadIdx.x] = (uint16_t)bk;
+        __syncthreads();
+        uint32_t rank = 0, same = 0;
+        if (i < hi) {
+            for (uint32_t j = 0; j < 256; ++j) { const bool eq = tile[j] == bk; same += eq; rank += eq && j < threadIdx.x; }
+            order[cursor[bk] + rank] = i;
+        }
+        __syncthreads();
+        if (i < hi && rank == same - 1) cursor[bk] += same;  // the last read of each bucket in this tile advances the cursor
     }
-}
-__global__ void k_len_scatter(const uint32_t *len1, const uint32_t *len2, uint32_t n, uint32_t *cursor, uint32_t *order) {
-    // block-aggregated: one global atomic per (block, bucket) instead of one per read (uniform-length batches put
-    // every read in the same bucket)
-    __shared__ uint32_t s_cnt[256], s_base[256];
-    s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t b = 0, local = 0;
-    if (i < n) { b = len_bucket(len1[i] + (len2 ? len2[i] : 0u)); local = atomicAdd(&s_cnt[b], 1u); }
-    __syncthreads();
-    if (s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], s_cnt[threadIdx.x]);
-    __syncthreads();
-    if (i < n) order[s_base[b] + local] = i;
 }
 
 // algorithmic bytes of a batch: sum ceil(L/4) + M*h*W*8 + (8 + 8C)
@@ -669,10 +743,11 @@ __global__ void k_synth_genomes(uint32_t *out, uint64_t n_dwords, uint64_t seed)
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_dwords; i += (uint64_t)gridDim.x * blockDim.x)
         out[i] = (uint32_t)mix64(seed ^ (i * 0xD1342543DE82EF95ULL));
 }
-__global__ void k_synth_fill(uint64_t *words, uint64_t n_rows, uint32_t W, uint32_t B, uint64_t seed, uint32_t thr16) {
+__global__ void k_synth_fill(uint64_t *words, uint64_t n_rows, uint64_t row_begin, uint32_t W, uint32_t B, uint64_t seed, uint32_t thr16) {
     // every bit of the user bins is set with probability thr16 / 65536 (four 16-bit lotteries per mix64)
     const uint64_t n_words = n_rows * W;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint64_t li = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; li < n_words; li += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = row_begin * W + li;  // global word index: a shard holds exactly the words of the full index
         const uint32_t w = (uint32_t)(i % W);
         uint64_t x = 0;
         for (uint32_t j = 0; j < 16; ++j) {
@@ -682,7 +757,7 @@ __global__ void k_synth_fill(uint64_t *words, uint64_t n_rows, uint32_t W, uint3
         }
         const uint32_t lo = w * 64;
         if (B < lo + 64) x &= (B <= lo) ? 0ULL : ((1ULL << (B - lo)) - 1);
-        words[i] = x;
+        words[li] = x;
     }
 }
 struct SynthReadsArgs {
@@ -816,6 +891,9 @@ struct chn_stream {
     // staging of host batches (large arrays; reused by the next batch in stream order)
     DevBuf d_bases, d_nmask, d_off1, d_off2;
     DevBuf d_order, d_hist, d_rows, d_rowown, d_wbase, d_wcount, d_model;
+    DevBuf d_list, d_cbase;           // row-sharded mode: minimiser value log, compact entry offsets
+    uint64_t shard_entries = 0;
+    bool shard_open = false;
     Slot slot[2];
     int head = 0;      // slot of the next submit
     int inflight = 0;  // batches submitted and not yet waited for (FIFO)
@@ -982,8 +1060,6 @@ static void host_model_call(const HostModel &M, uint32_t nh, const uint32_t *cnt
 extern "C" int chn_stream_create(chn_index *idx, const chn_stream_cfg *cfg, chn_stream **out) {
     if (!idx || !cfg || !out || cfg->struct_size != sizeof(chn_stream_cfg)) return fail(CHN_E_INVALID, "chn_stream_create: bad argument");
     if (cfg->max_reads == 0 || cfg->max_reads > 0xFFFFFF00ULL) return fail(CHN_E_INVALID, "max_reads out of range");
-    if (idx->d.row_begin != 0 || idx->d.row_end != idx->d.bin_size)
-        return fail(CHN_E_INVALID, "a classification stream needs an index object holding all rows (row-sharded objects are probe-only)");
     HIPCHK(hipSetDevice(idx->d.device));
     chn_stream *s = new (std::nothrow) chn_stream();
     if (!s) return fail(CHN_E_NOMEM, "host allocation failed");
@@ -1005,8 +1081,9 @@ extern "C" int chn_stream_create(chn_index *idx, const chn_stream_cfg *cfg, chn_
             return rc;
         }
     }
-    if ((rc = s->d_order.ensure(n * 4)) || (rc = s->d_hist.ensure(256 * 4))) { chn_stream_destroy(s); return rc; }
-    const bool fused = idx->single_bin_categories && C <= 8 && idx->d.bin_words == 1;
+    if ((rc = s->d_order.ensure(n * 4)) || (rc = s->d_hist.ensure(LEN_BLOCKS * 256 * 4))) { chn_stream_destroy(s); return rc; }
+    const bool sharded = idx->d.row_begin != 0 || idx->d.row_end != idx->d.bin_size;
+    const bool fused = !sharded && idx->single_bin_categories && C <= 8 && idx->d.bin_words == 1;
     if (!fused) {
         const uint64_t nw = (n + WAVE - 1) / WAVE;
         if ((rc = s->d_rows.ensure(cfg->max_bases * idx->d.bin_words * 8)) || (rc = s->d_rowown.ensure(cfg->max_bases)) ||
@@ -1030,7 +1107,7 @@ extern "C" int chn_stream_destroy(chn_stream *s) {
                           &sl.d_len1, &sl.d_len2, &sl.d_mq, &sl.d_comp};
         for (DevBuf *b : bufs) b->release();
     }
-    DevBuf *bufs[] = {&s->d_bases, &s->d_nmask, &s->d_off1, &s->d_off2, &s->d_order, &s->d_hist, &s->d_rows, &s->d_rowown, &s->d_wbase, &s->d_wcount, &s->d_model};
+    DevBuf *bufs[] = {&s->d_bases, &s->d_nmask, &s->d_off1, &s->d_off2, &s->d_order, &s->d_hist, &s->d_rows, &s->d_rowown, &s->d_wbase, &s->d_wcount, &s->d_model, &s->d_list, &s->d_cbase};
     for (DevBuf *b : bufs) b->release();
     delete s;
     return CHN_OK;
@@ -1120,8 +1197,15 @@ static int upload(DevBuf &buf, const void *src, size_t bytes, hipStream_t st) {
     return CHN_OK;
 }
 
-extern "C" int chn_batch_submit(chn_stream *s, const chn_batch *b) {
+// count (general layouts) + model/call + byte counter; closes the batch in slot `sl`
+static int launch_tail(chn_stream *s, Slot &sl, bool fused);
+
+// list_mode: stop after logging the minimiser VALUES (row-sharded mode); otherwise the whole chain
+static int submit_impl(chn_stream *s, const chn_batch *b, bool list_mode) {
     if (!s || !b || b->struct_size != sizeof(chn_batch)) return fail(CHN_E_INVALID, "chn_batch_submit: bad argument");
+    if (!list_mode && (s->idx->d.row_begin != 0 || s->idx->d.row_end != s->idx->d.bin_size))
+        return fail(CHN_E_INVALID, "chn_batch_submit needs an index object holding all rows; use the chn_shard_* calls with a row shard");
+    if (list_mode && s->inflight) return fail(CHN_E_STATE, "chn_shard_minimise: batches are in flight");
     if (s->inflight >= 2) return fail(CHN_E_STATE, "two batches already in flight: call chn_batch_wait first");
     if (b->n_reads == 0) return fail(CHN_E_INVALID, "empty batch");
     if (b->n_reads > s->cfg.max_reads || b->n_bases > s->cfg.max_bases) return fail(CHN_E_CAPACITY, "batch exceeds stream capacity");
@@ -1133,7 +1217,7 @@ extern "C" int chn_batch_submit(chn_stream *s, const chn_batch *b) {
     const uint64_t n = b->n_reads;
     const bool paired = b->seg2_offset != nullptr;
     const uint32_t W = (uint32_t)d.bin_words, C = d.num_categories;
-    const bool fused = s->idx->single_bin_categories && C <= 8 && W == 1;
+    const bool fused = !list_mode && s->idx->single_bin_categories && C <= 8 && W == 1;
     Slot &sl = s->slot[s->head];
     sl.host_batch = !b->on_device;
     const uint32_t *bases, *nmask;
@@ -1175,23 +1259,22 @@ extern "C" int chn_batch_submit(chn_stream *s, const chn_batch *b) {
     if (prof) HIPCHK(hipEventRecord(sl.ev[6], s->stream));
 
     // 1. length-class ordering
-    HIPCHK(hipMemsetAsync(s->d_hist.p, 0, 256 * 4, s->stream));
-    hipLaunchKernelGGL(k_len_hist, dim3(std::min<uint64_t>(1024, (n + 255) / 256)), dim3(256), 0, s->stream, sl.len1, sl.len2, (uint32_t)n, s->d_hist.as<uint32_t>());
-    hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(64), 0, s->stream, s->d_hist.as<uint32_t>());
-    hipLaunchKernelGGL(k_len_scatter, dim3((n + 255) / 256), dim3(256), 0, s->stream, sl.len1, sl.len2, (uint32_t)n, s->d_hist.as<uint32_t>(), s->d_order.as<uint32_t>());
+    hipLaunchKernelGGL(k_len_hist, dim3(LEN_BLOCKS), dim3(256), 0, s->stream, sl.len1, sl.len2, (uint32_t)n, s->d_hist.as<uint32_t>());
+    hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, s->stream, s->d_hist.as<uint32_t>());
+    hipLaunchKernelGGL(k_len_scatter, dim3(LEN_BLOCKS), dim3(256), 0, s->stream, sl.len1, sl.len2, (uint32_t)n, s->d_hist.as<uint32_t>(), s->d_order.as<uint32_t>());
     HIPCHK(hipGetLastError());
 
     // 2. minimise + probe
     K1Args a;
     std::memset(&a, 0, sizeof(a));
-    a.words = s->idx->words; a.S = d.bin_size; a.row_begin = d.row_begin; a.seed = d.minimiser_seed; a.powk1 = pow5(d.kmer_size - 1);
+    a.words = s->idx->words; a.S = d.bin_size; a.row_begin = d.row_begin; a.row_end = d.row_end; a.seed = d.minimiser_seed; a.powk1 = pow5(d.kmer_size - 1);
     a.shift = (uint32_t)d.hash_shift; a.h = d.hash_funs; a.k = d.kmer_size; a.wn = d.window_size - d.kmer_size + 1;
     a.n_reads = (uint32_t)n; a.nseg = paired ? 2 : 1; a.B = (uint32_t)d.bins; a.C = C;
     for (uint32_t bb = 0; bb < 8 && bb < d.bins; ++bb) a.b2c_packed |= (uint64_t)d.bin_to_category[bb] << (8 * bb);
     a.bases = bases; a.nmask = nmask; a.off1 = off1; a.off2 = off2; a.len1 = sl.len1; a.len2 = sl.len2;
     a.order = s->d_order.as<uint32_t>();
     a.num_hashes = sl.d_num_hashes.as<uint32_t>(); a.counts = sl.d_counts.as<uint32_t>(); a.unique = sl.d_unique.as<uint32_t>();
-    a.rows = s->d_rows.as<uint64_t>(); a.row_owner = s->d_rowown.as<uint8_t>();
+    a.rows = list_mode ? s->d_list.as<uint64_t>() : s->d_rows.as<uint64_t>(); a.row_owner = s->d_rowown.as<uint8_t>();
     a.wave_base = s->d_wbase.as<uint64_t>(); a.wave_count = s->d_wcount.as<uint32_t>();
     const uint32_t n_waves = (uint32_t)((n + WAVE - 1) / WAVE);
     if (!fused) {
@@ -1200,14 +1283,25 @@ extern "C" int chn_batch_submit(chn_stream *s, const chn_batch *b) {
         hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s->stream, s->d_wbase.as<uint64_t>(), n_waves);
         HIPCHK(hipGetLastError());
     }
-    const int mode = fused ? MODE_FUSED : MODE_ROWS;
+    const int mode = list_mode ? MODE_LIST : fused ? MODE_FUSED : MODE_ROWS;
     const size_t lds = k1_lds_bytes(a.wn, C, mode);
     if (lds > 160 * 1024) return fail(CHN_E_INVALID, "window too large for LDS");
     if (prof) { HIPCHK(hipEventRecord(sl.ev[0], s->stream)); }
-    hipError_t e = fused ? launch_k1_w<MODE_FUSED>(W, a, lds, s->stream) : launch_k1_w<MODE_ROWS>(W, a, lds, s->stream);
+    hipError_t e = list_mode ? launch_k1<1, MODE_LIST>(a, lds, s->stream)
+                             : fused ? launch_k1_w<MODE_FUSED>(W, a, lds, s->stream) : launch_k1_w<MODE_ROWS>(W, a, lds, s->stream);
     if (e != hipSuccess) return fail(CHN_E_HIP, std::string("k_minimise_probe launch: ") + hipGetErrorString(e));
     if (prof) { HIPCHK(hipEventRecord(sl.ev[1], s->stream)); sl.ev_used[0] = true; }
 
+    if (list_mode) return CHN_OK;  // the caller continues with chn_shard_probe / chn_shard_finish
+    return launch_tail(s, sl, fused);
+}
+
+static int launch_tail(chn_stream *s, Slot &sl, bool fused) {
+    const chn_index_desc &d = s->idx->d;
+    const uint64_t n = sl.n_reads;
+    const uint32_t W = (uint32_t)d.bin_words, C = d.num_categories;
+    const uint32_t n_waves = (uint32_t)((n + WAVE - 1) / WAVE);
+    const bool prof = (s->cfg.flags & CHN_STREAM_PROFILE) != 0;
     // 3. counts from rows (general bin layouts)
     if (!fused) {
         K2Args k2;
@@ -1261,6 +1355,87 @@ extern "C" int chn_batch_submit(chn_stream *s, const chn_batch *b) {
     s->head ^= 1;
     s->inflight += 1;
     return CHN_OK;
+}
+
+extern "C" int chn_batch_submit(chn_stream *s, const chn_batch *b) { return submit_impl(s, b, false); }
+
+// ---- row-sharded mode -----------------------------------------------------------------------------
+static int ensure_shard_buffers(chn_stream *s) {
+    const uint64_t nw = (s->cfg.max_reads + WAVE - 1) / WAVE;
+    int rc;
+    if ((rc = s->d_list.ensure(s->cfg.max_bases * 8)) || (rc = s->d_cbase.ensure((nw + 1) * 8))) return rc;
+    if ((rc = s->d_rows.ensure(s->cfg.max_bases * s->idx->d.bin_words * 8)) || (rc = s->d_rowown.ensure(s->cfg.max_bases)) ||
+        (rc = s->d_wbase.ensure(nw * 8)) || (rc = s->d_wcount.ensure(nw * 4))) return rc;
+    return CHN_OK;
+}
+static ShardArgs shard_args(chn_stream *s, const chn_index *shard, uint64_t *partial) {
+    ShardArgs a;
+    std::memset(&a, 0, sizeof a);
+    const chn_index_desc &d = shard->d;
+    a.list = s->d_list.as<uint64_t>(); a.wave_base = s->d_wbase.as<uint64_t>(); a.cbase = s->d_cbase.as<uint64_t>();
+    a.wave_count = s->d_wcount.as<uint32_t>(); a.words = shard->words; a.S = d.bin_size; a.row_begin = d.row_begin; a.row_end = d.row_end;
+    a.shift = (uint32_t)d.hash_shift; a.h = d.hash_funs; a.W = (uint32_t)d.bin_words; a.partial = partial; a.rows = s->d_rows.as<uint64_t>();
+    return a;
+}
+
+extern "C" int chn_shard_minimise(chn_stream *s, const chn_batch *b, uint64_t *n_entries) {
+    if (!s || !b || !n_entries) return fail(CHN_E_INVALID, "chn_shard_minimise: null argument");
+    if (s->shard_open) return fail(CHN_E_STATE, "chn_shard_minimise: previous sharded batch not finished");
+    HIPCHK(hipSetDevice(s->idx->d.device));
+    int rc = ensure_shard_buffers(s);
+    if (rc) return rc;
+    if ((rc = submit_impl(s, b, true))) return rc;
+    const uint32_t n_waves = (uint32_t)((b->n_reads + WAVE - 1) / WAVE);
+    hipLaunchKernelGGL(k_counts_to_u64, dim3((n_waves + 1 + 255) / 256), dim3(256), 0, s->stream, s->d_wcount.as<uint32_t>(), n_waves, s->d_cbase.as<uint64_t>());
+    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s->stream, s->d_cbase.as<uint64_t>(), n_waves + 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
+    uint64_t total = 0;
+    HIPCHK(hipMemcpy(&total, s->d_cbase.as<uint64_t>() + n_waves, 8, hipMemcpyDeviceToHost));
+    s->shard_entries = total;
+    s->shard_open = true;
+    *n_entries = total;
+    return CHN_OK;
+}
+
+extern "C" int chn_shard_probe(chn_stream *s, const chn_index *shard, uint64_t *dev_partial, uint64_t capacity_words) {
+    if (!s || !shard || !dev_partial) return fail(CHN_E_INVALID, "chn_shard_probe: null argument");
+    if (!s->shard_open) return fail(CHN_E_STATE, "chn_shard_probe: call chn_shard_minimise first");
+    const chn_index_desc &a = s->idx->d, &c = shard->d;
+    if (a.bin_size != c.bin_size || a.bin_words != c.bin_words || a.hash_funs != c.hash_funs || a.device != c.device)
+        return fail(CHN_E_INVALID, "chn_shard_probe: shard does not belong to the stream's index");
+    if (capacity_words < s->shard_entries * c.hash_funs * c.bin_words) return fail(CHN_E_CAPACITY, "chn_shard_probe: partial buffer too small");
+    HIPCHK(hipSetDevice(a.device));
+    const Slot &sl = s->slot[s->head];
+    const uint32_t n_waves = (uint32_t)((sl.n_reads + WAVE - 1) / WAVE);
+    const ShardArgs sa = shard_args(s, shard, dev_partial);
+    switch (c.bin_words) {
+        case 1: hipLaunchKernelGGL(k_probe_partial<1>, dim3(n_waves), dim3(256), 0, s->stream, sa); break;
+        case 2: hipLaunchKernelGGL(k_probe_partial<2>, dim3(n_waves), dim3(256), 0, s->stream, sa); break;
+        case 3: hipLaunchKernelGGL(k_probe_partial<3>, dim3(n_waves), dim3(256), 0, s->stream, sa); break;
+        default: hipLaunchKernelGGL(k_probe_partial<4>, dim3(n_waves), dim3(256), 0, s->stream, sa); break;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));  // the caller's collective runs on its own stream
+    return CHN_OK;
+}
+
+extern "C" int chn_shard_finish(chn_stream *s, const uint64_t *dev_partial) {
+    if (!s || !dev_partial) return fail(CHN_E_INVALID, "chn_shard_finish: null argument");
+    if (!s->shard_open) return fail(CHN_E_STATE, "chn_shard_finish: no sharded batch open");
+    HIPCHK(hipSetDevice(s->idx->d.device));
+    Slot &sl = s->slot[s->head];
+    const uint32_t n_waves = (uint32_t)((sl.n_reads + WAVE - 1) / WAVE);
+    const ShardArgs sa = shard_args(s, s->idx, const_cast<uint64_t *>(dev_partial));
+    switch (s->idx->d.bin_words) {
+        case 1: hipLaunchKernelGGL(k_and_partial<1>, dim3(n_waves), dim3(256), 0, s->stream, sa); break;
+        case 2: hipLaunchKernelGGL(k_and_partial<2>, dim3(n_waves), dim3(256), 0, s->stream, sa); break;
+        case 3: hipLaunchKernelGGL(k_and_partial<3>, dim3(n_waves), dim3(256), 0, s->stream, sa); break;
+        default: hipLaunchKernelGGL(k_and_partial<4>, dim3(n_waves), dim3(256), 0, s->stream, sa); break;
+    }
+    HIPCHK(hipGetLastError());
+    s->shard_open = false;
+    return launch_tail(s, sl, false);
 }
 
 extern "C" int chn_stream_sync(chn_stream *s) {
@@ -1395,14 +1570,13 @@ extern "C" int chn_synth_fill_index(chn_index *idx, uint64_t seed, double densit
     if (!idx || density < 0 || density > 1) return fail(CHN_E_INVALID, "chn_synth_fill_index: bad argument");
     HIPCHK(hipSetDevice(idx->d.device));
     const uint32_t thr = (uint32_t)std::lround(density * 65536.0);
-    hipLaunchKernelGGL(k_synth_fill, dim3(8192), dim3(256), 0, 0, idx->words, idx->rows_local, (uint32_t)idx->d.bin_words, (uint32_t)idx->d.bins, seed, thr);
+    hipLaunchKernelGGL(k_synth_fill, dim3(8192), dim3(256), 0, 0, idx->words, idx->rows_local, idx->d.row_begin, (uint32_t)idx->d.bin_words, (uint32_t)idx->d.bins, seed, thr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     return CHN_OK;
 }
 extern "C" int chn_synth_plant(chn_index *idx, const uint32_t *dev_bases2, uint64_t n_genomes, uint64_t genome_len, const uint8_t *genome_bin) {
     if (!idx || !dev_bases2 || !genome_bin || genome_len % 64) return fail(CHN_E_INVALID, "chn_synth_plant: bad argument");
-    if (idx->d.row_begin != 0 || idx->d.row_end != idx->d.bin_size) return fail(CHN_E_INVALID, "plant needs the whole index");
     const chn_index_desc &d = idx->d;
     HIPCHK(hipSetDevice(d.device));
     // The set of minimisers of a sequence equals the union over overlapping chunks (every window lies in one chunk),
@@ -1423,7 +1597,7 @@ extern "C" int chn_synth_plant(chn_index *idx, const uint32_t *dev_bases2, uint6
     hipLaunchKernelGGL(k_chunk_layout, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, n_genomes, genome_len, chunk, overlap, cpg, off, len);
     K1Args a;
     std::memset(&a, 0, sizeof(a));
-    a.words = idx->words; a.words_rw = idx->words; a.S = d.bin_size; a.row_begin = 0; a.seed = d.minimiser_seed; a.powk1 = pow5(d.kmer_size - 1);
+    a.words = idx->words; a.words_rw = idx->words; a.S = d.bin_size; a.row_begin = d.row_begin; a.row_end = d.row_end; a.seed = d.minimiser_seed; a.powk1 = pow5(d.kmer_size - 1);
     a.shift = (uint32_t)d.hash_shift; a.h = d.hash_funs; a.k = d.kmer_size; a.wn = d.window_size - d.kmer_size + 1;
     a.n_reads = (uint32_t)n; a.nseg = 1; a.B = (uint32_t)d.bins; a.C = d.num_categories;
     a.bases = dev_bases2; a.off1 = off; a.len1 = len; a.read_bin = bin;
@@ -1477,6 +1651,17 @@ extern "C" int chn_synth_reads(int device, uint64_t seed, const uint32_t *dev_ge
     hipLaunchKernelGGL(k_synth_reads, dim3((max_dwords + 63) / 64, gy, gz), dim3(64), 0, 0, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
+    return CHN_OK;
+}
+extern "C" int chn_device_malloc(int device, uint64_t bytes, void **ptr) {
+    if (!ptr) return fail(CHN_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMalloc(ptr, bytes ? bytes : 16));
+    return CHN_OK;
+}
+extern "C" int chn_device_upload(int device, void *dev_dst, const void *host_src, uint64_t bytes) {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
     return CHN_OK;
 }
 extern "C" int chn_device_free(int device, void *ptr) {

@@ -178,6 +178,20 @@ int chn_classify_counts(chn_stream *s, uint64_t n_reads, const uint32_t *num_has
                         const uint32_t *unique_counts, const uint32_t *lengths, const float *mean_quality,
                         const float *compression, double *probabilities, uint8_t *call, uint8_t *confidence);
 
+/* ---- row-sharded ("hash-bin" sharded) mode ---------------------------------------------------------------
+ * For an index too large for one GPU: rank r creates a chn_index with row_begin/row_end = its slice and a stream on it.
+ * Per batch, on EVERY rank and for the SAME batch:
+ *   1. chn_shard_minimise   all reads are minimised (redundantly); returns E = number of minimisers of the batch
+ *   2. chn_shard_probe      partial[e][i][w] = word w of row hash_i(minimiser e) if this rank owns the row, else 0
+ *   3. the caller sums `partial` (E*h*W uint64) over ranks with ONE all-reduce (RCCL; sum == select because exactly
+ *      one rank owns each row) -- the library itself has no RCCL dependency
+ *   4. chn_shard_finish     AND over the h hash functions, counts, model+call; then chn_batch_wait as usual.
+ * `dev_partial` is a device buffer of the caller (e.g. a torch tensor). No reference counterpart (the reference is
+ * single-process); replaces the same loop body as chn_batch_submit. */
+int chn_shard_minimise(chn_stream *s, const chn_batch *b, uint64_t *n_entries);
+int chn_shard_probe(chn_stream *s, const chn_index *shard, uint64_t *dev_partial, uint64_t capacity_words);
+int chn_shard_finish(chn_stream *s, const uint64_t *dev_partial);
+
 /* Per-kernel device time accumulated since the last reset (CHN_STREAM_PROFILE streams only).
  * which: 0 = minimise+probe kernel, 1 = count kernel, 2 = model+call kernel, 3 = whole batch chain. */
 int chn_stream_profile(chn_stream *s, int which, double *total_ms, uint64_t *launches, int reset);
@@ -208,7 +222,9 @@ typedef struct chn_synth_reads_out {
 int chn_synth_reads(int device, uint64_t seed, const uint32_t *dev_genomes, uint64_t n_genomes, uint64_t genome_len,
                     uint64_t first_read_id, uint64_t n_reads, uint32_t read_len_min, uint32_t read_len_max, double sub_rate,
                     double random_fraction, float mean_quality, chn_synth_reads_out *out);
+int chn_device_malloc(int device, uint64_t bytes, void **ptr);
 int chn_device_free(int device, void *ptr);
+int chn_device_upload(int device, void *dev_dst, const void *host_src, uint64_t bytes);
 int chn_device_download(int device, void *host_dst, const void *dev_src, uint64_t bytes);
 
 const char *chn_last_error(void);

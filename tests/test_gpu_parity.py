@@ -223,3 +223,63 @@ def test_batch_properties_order_and_repeat(api, oracle_lib):
     util.assert_parity({k: v[pick] for k, v in a.items() if k != "flags"}, orc)
     g.destroy()
     oidx.free()
+
+
+def test_row_sharded_mode_equals_replica_mode(api, oracle_lib):
+    """north-star config 4 on one GPU: two row shards of the index, per-shard partial probe words, their SUM (what the
+    RCCL all-reduce computes; exactly one shard owns each row) fed back -> identical to the whole-index path and the oracle"""
+    from charon_amd import pack
+    r = util.rng(31)
+    for B, cats in ((2, [0, 1]), (70, [i % 2 for i in range(70)])):
+        gs = [util.random_seq(r, 2500) for _ in range(B)]
+        oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], cats, ["host", "microbial"], bin_size=30011, fill_seed=3, fill=0.05)
+        reads = util.sample_reads(r, gs, 300, (50, 2000), sub_rate=0.03) + [b"A" * 300, b""]
+        orc = run_oracle(oidx, reads)
+        S, Wd = oidx.bin_size, oidx.bin_words
+        cut = S // 3
+        words = oidx.words()
+        shards = []
+        for lo, hi in ((0, cut), (cut, S)):
+            d = api.make_desc(oidx.bins, S, oidx.bin_to_cat, 2, 0, row_begin=lo, row_end=hi)
+            sh = api.Index(d)
+            sh.upload(words[lo * Wd:hi * Wd], row_begin=lo)
+            shards.append(sh)
+        p = pack.pack_reads(reads)
+        n = len(reads)
+        # one stream per shard, as two ranks would have: both minimise the same batch independently, so the entry order of
+        # the two partial buffers must agree (deterministic length ordering + emission order)
+        sts = [api.Stream(sh, n, p["n_bases"]) for sh in shards]
+        for st in sts:
+            st.set_model(api.default_model(2, 0))
+        Es = [st.shard_minimise_host(p) for st in sts]
+        E = Es[0]
+        assert Es[0] == Es[1] == int(orc["num_hashes"].sum())
+        nwords = E * 3 * Wd
+        bufs = [api.device_malloc(0, nwords * 8) for _ in shards]
+        for st, sh, buf in zip(sts, shards, bufs):
+            st.shard_probe(sh, buf, nwords)
+        parts = [api.device_download(0, buf, nwords * 8, np.uint64) for buf in bufs]
+        # a word is non-zero in at most one shard's partial buffer
+        assert not np.any((parts[0] != 0) & (parts[1] != 0))
+        total = parts[0] + parts[1]
+        outs = []
+        for st, buf in zip(sts, bufs):
+            api.device_upload(0, buf, total)
+            st.shard_finish(buf)
+            outs.append(st.wait_host())
+        gpu = outs[0]
+        for key in ("num_hashes", "counts", "unique", "call", "conf"):
+            assert np.array_equal(outs[0][key], outs[1][key])
+        st = sts[0]
+        sts[1].destroy()
+        # mean quality / compression were not passed: gate on the same values in the oracle comparison
+        thr = oracle_lib.default_thresholds()
+        seqs, offs, _ = util.concat(reads)
+        orc0 = oidx.process_reads(seqs, offs, mq_const=0.0, thr=thr)
+        util.assert_parity(gpu, orc0)
+        for buf in bufs:
+            api.device_free(0, buf)
+        st.destroy()
+        for sh in shards:
+            sh.destroy()
+        oidx.free()

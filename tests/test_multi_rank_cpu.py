@@ -59,3 +59,43 @@ def test_shard_range_properties():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard.shard_range(10, 2, 2)
+
+
+def _shard_worker(rank, world, initfile, outdir):
+    """row-sharded mode on CPU: each rank fills partial[e][i][w] only for rows it owns; the gloo SUM all-reduce must
+    reconstruct every probe word exactly (one owner per row), and the AND over hash functions must equal bulk_contains"""
+    import torch
+    import torch.distributed as dist
+    from charon_amd import shard
+    from oracle import pyoracle as po
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    r = util.rng(5)
+    gs = [util.random_seq(r, 3000) for _ in range(70)]
+    oidx = util.build_oracle_index(po, [[g] for g in gs], [i % 2 for i in range(70)], ["host", "microbial"], bin_size=5003)
+    words, W, S = oidx.words(), oidx.bin_words, oidx.bin_size
+    mins = np.concatenate([po.minimisers(g[:800].decode()) for g in gs[:6]])
+    lo, hi = shard.shard_range(S, rank, world)
+    partial = np.zeros((len(mins), 3, W), dtype=np.int64)
+    for e, v in enumerate(mins):
+        for i in range(3):
+            row = po.lib().orc_hash_and_fit(int(v), i, S)
+            if lo <= row < hi:
+                partial[e, i] = words[row * W:(row + 1) * W].view(np.int64)
+    t = torch.from_numpy(partial)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    full = t.numpy().view(np.uint64)
+    rows = full[:, 0] & full[:, 1] & full[:, 2]
+    want = np.stack([oidx.bulk_contains(int(v)) for v in mins])
+    ok = bool(np.array_equal(rows, want))
+    np.save(os.path.join(outdir, "s%d.npy" % rank), np.array([int(ok), lo, hi]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_probe_words_sum_reconstructs(oracle_lib):
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_shard_worker, args=(2, os.path.join(d, "init"), d), nprocs=2, join=True)
+        a, b = np.load(os.path.join(d, "s0.npy")), np.load(os.path.join(d, "s1.npy"))
+    assert a[0] == 1 and b[0] == 1
+    assert (a[1], a[2], b[1], b[2]) == (0, 2502, 2502, 5003)
