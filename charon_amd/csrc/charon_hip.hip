@@ -571,7 +571,7 @@ struct K3Args {
     double *prob;
     uint8_t *call, *conf, *flags;
     const float *data;            // all KDE datasets back to back
-    uint32_t pos_off[8], pos_n[8], neg_off[8], neg_n[8];   // C <= 8 on the device path
+    const uint32_t *tab;          // [4][C]: pos_off, pos_n, neg_off, neg_n per category
     uint32_t n_reads, C;
     float h_pos, h_neg, log_rate, rate;
     float min_quality, min_compression, cpt, lo_thr, min_pd, min_prd;
@@ -581,14 +581,31 @@ struct K3Args {
 };
 
 __device__ __forceinline__ float kde_prob_dev(const float *data, uint32_t n, float h, float x) {
-    // KDEParams::prob / K (include/classify_stats.hpp:242-252): K evaluated in double, accumulated in float
+    // KDEParams::prob / K (include/classify_stats.hpp:242-252): K evaluated in double, accumulated in float.
+    // A term with |t| > 15 is exp(-112.5)/sqrt(2 pi) < 6e-50, which rounds to +0.0f, and adding +0.0f leaves the float
+    // accumulator unchanged -- skipping it is exact (it removes most of the h = 0.001 terms).  NaN compares false.
     float total = 0.0f;
     for (uint32_t i = 0; i < n; ++i) {
         const float t = (x - data[i]) / h;
+        if (fabsf(t) > 15.0f) continue;
         const double kd = exp(-((double)t * (double)t) / 2.0) / sqrt(2 * 3.141592653589793238463);
         total += (float)kd;
     }
     return total / (h * (float)n);
+}
+
+// Model::prob (include/classify_stats.hpp:370-389) of category c for a read with `uq` unique hits out of `nh` minimisers
+__device__ __forceinline__ double model_prob_dev(const K3Args &a, uint32_t c, uint32_t uq, uint32_t nh) {
+    const float x = (float)uq / (float)nh;  // unique proportion (include/read_entry.hpp:140-150)
+    float p_err;
+    if (x != x) p_err = x;
+    else if (x < 0.0f) p_err = 0.0f;
+    else p_err = (float)exp((double)(a.log_rate - a.rate * x));  // stats::dexp(x, 300) = exp(log(300) - 300 x)
+    float p_pos = kde_prob_dev(a.data + a.tab[c], a.tab[a.C + c], a.h_pos, x);
+    const float p_neg = kde_prob_dev(a.data + a.tab[2 * a.C + c], a.tab[3 * a.C + c], a.h_neg, x);
+    if (x == 1.0f) p_pos = 1.0f;
+    const float total = p_err + p_pos + p_neg;
+    return (double)(p_pos / total);  // probabilities_ starts at 1 and is multiplied once (:56,277)
 }
 
 __global__ __launch_bounds__(256) void k_model_call(const K3Args a) {
@@ -596,27 +613,9 @@ __global__ __launch_bounds__(256) void k_model_call(const K3Args a) {
     if (r >= a.n_reads) return;
     const uint32_t C = a.C;
     const uint32_t nh = a.num_hashes[r];
-    double prob[8];
-    float props[8], uprops[8];
-    uint32_t cnts[8], uq[8];
-    for (uint32_t c = 0; c < C; ++c) {
-        cnts[c] = a.counts[(size_t)r * C + c];
-        uq[c] = a.unique[(size_t)r * C + c];
-        props[c] = (float)cnts[c] / (float)nh;   // get_proportions (include/read_entry.hpp:140-150)
-        uprops[c] = (float)uq[c] / (float)nh;
-        const float x = uprops[c];
-        // Model::prob (include/classify_stats.hpp:370-389)
-        float p_err;
-        if (x != x) p_err = x;
-        else if (x < 0.0f) p_err = 0.0f;
-        else p_err = (float)exp((double)(a.log_rate - a.rate * x));  // stats::dexp(x, 300) = exp(log(300) - 300 x)
-        float p_pos = kde_prob_dev(a.data + a.pos_off[c], a.pos_n[c], a.h_pos, x);
-        const float p_neg = kde_prob_dev(a.data + a.neg_off[c], a.neg_n[c], a.h_neg, x);
-        if (x == 1.0f) p_pos = 1.0f;
-        const float total = p_err + p_pos + p_neg;
-        prob[c] = (double)(p_pos / total);       // probabilities_ starts at 1 and is multiplied once (:56,277)
-        a.prob[(size_t)r * C + c] = prob[c];
-    }
+    const uint32_t *cnts = a.counts + (size_t)r * C, *uq = a.unique + (size_t)r * C;
+    double *prob = a.prob + (size_t)r * C;
+    for (uint32_t c = 0; c < C; ++c) prob[c] = model_prob_dev(a, c, uq[c], nh);
     const float mq = a.mean_quality ? a.mean_quality[r] : 0.0f;
     const float comp = a.compression ? a.compression[r] : 0.0f;
     const uint32_t length = a.len1[r] + (a.len2 ? a.len2[r] : 0u);
@@ -625,7 +624,7 @@ __global__ __launch_bounds__(256) void k_model_call(const K3Args a) {
     if (!a.paired) {
         // call_host (include/read_entry.hpp:218-269)
         const uint32_t host = a.host_index, other = 1u - host;
-        const double hu = uprops[host], ou = uprops[other], hp = prob[host], op = prob[other];
+        const double hu = (float)uq[host] / (float)nh, ou = (float)uq[other] / (float)nh, hp = prob[host], op = prob[other];
         uint32_t first = host, second = other;
         if (hu < ou) { first = other; second = host; }
         const uint32_t raw = uq[first] - uq[second];
@@ -657,12 +656,14 @@ __global__ __launch_bounds__(256) void k_model_call(const K3Args a) {
         conf = raw > 255u ? 255u : raw;
         const bool gate = !(mq < a.min_quality) && !(length < a.min_length) && !(comp < a.min_compression);
         if (gate) {
-            if (prob[second] == 0 && prob[first] > 0) call = (uint8_t)first;
-            else if ((int32_t)conf > a.conf_thr && prob[first] > prob[second]) call = (uint8_t)first;
+            const double pf = prob[first], ps = prob[second];
+            const float propf = (float)cnts[first] / (float)nh, props = (float)cnts[second] / (float)nh;
+            if (ps == 0 && pf > 0) call = (uint8_t)first;
+            else if ((int32_t)conf > a.conf_thr && pf > ps) call = (uint8_t)first;
             if (cnts[second] > cnts[first] || cnts[first] - cnts[second] < a.min_hits) call = 255;
-            if (props[second] > props[first] || props[first] - props[second] < a.min_pd) call = 255;
-            const double scale = fmax(fabs(prob[first]), fabs(prob[second]));
-            if (fabs(prob[first] - prob[second]) <= 2e-6 * fmax(scale, 1e-300)) flag = 1;
+            if (props > propf || propf - props < a.min_pd) call = 255;
+            const double scale = fmax(fabs(pf), fabs(ps));
+            if (fabs(pf - ps) <= 2e-6 * fmax(scale, 1e-300)) flag = 1;
         }
     }
     a.call[r] = call;
@@ -1117,7 +1118,6 @@ extern "C" int chn_model_set(chn_stream *s, const chn_model *m) {
     if (!s || !m || m->struct_size != sizeof(chn_model)) return fail(CHN_E_INVALID, "chn_model_set: bad argument");
     const uint32_t C = m->num_categories;
     if (C != s->idx->d.num_categories) return fail(CHN_E_INVALID, "model category count differs from the index");
-    if (C > 8) return fail(CHN_E_INVALID, "the device model+call kernel supports at most 8 categories");
     if (!m->paired && (C < 2 || m->host_index > 1))
         return fail(CHN_E_INVALID, "single-end dehost (call_host) needs the host category at index 0 or 1 of a >= 2 category index");
     if (m->paired && C < 2) return fail(CHN_E_INVALID, "call_category needs at least 2 categories");
@@ -1139,21 +1139,25 @@ extern "C" int chn_model_set(chn_stream *s, const chn_model *m) {
     M.min_pd = m->min_proportion_difference; M.min_prd = m->min_prob_difference;
     std::vector<float> flat;
     flat.reserve(total);
+    std::vector<uint32_t> tab(4 * (size_t)C);
     K3Args &k = s->k3;
     std::memset(&k, 0, sizeof(k));
     for (uint32_t c = 0; c < C; ++c) {
-        k.pos_off[c] = (uint32_t)flat.size(); k.pos_n[c] = (uint32_t)M.pos[c].size();
+        tab[c] = (uint32_t)flat.size(); tab[C + c] = (uint32_t)M.pos[c].size();
         flat.insert(flat.end(), M.pos[c].begin(), M.pos[c].end());
-        k.neg_off[c] = (uint32_t)flat.size(); k.neg_n[c] = (uint32_t)M.neg[c].size();
+        tab[2 * C + c] = (uint32_t)flat.size(); tab[3 * C + c] = (uint32_t)M.neg[c].size();
         flat.insert(flat.end(), M.neg[c].begin(), M.neg[c].end());
     }
     if (s->inflight) return fail(CHN_E_STATE, "chn_model_set: batches are in flight");
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipStreamSynchronize(s->stream2));
-    int rc = s->d_model.ensure(std::max<size_t>(flat.size() * 4, 4));
+    const size_t tab_bytes = tab.size() * 4;
+    int rc = s->d_model.ensure(tab_bytes + std::max<size_t>(flat.size() * 4, 4));
     if (rc) return rc;
-    HIPCHK(hipMemcpy(s->d_model.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
-    k.data = s->d_model.as<float>();
+    HIPCHK(hipMemcpy(s->d_model.p, tab.data(), tab_bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(static_cast<char *>(s->d_model.p) + tab_bytes, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
+    k.tab = s->d_model.as<uint32_t>();
+    k.data = reinterpret_cast<const float *>(static_cast<char *>(s->d_model.p) + tab_bytes);
     k.C = C; k.h_pos = M.h_pos; k.h_neg = M.h_neg; k.rate = M.rate; k.log_rate = std::log(M.rate);
     k.min_quality = M.min_quality; k.min_compression = M.min_compression; k.cpt = M.cpt; k.lo_thr = M.lo_thr;
     k.min_pd = M.min_pd; k.min_prd = M.min_prd; k.min_length = M.min_length; k.conf_thr = (int32_t)M.conf_thr;

@@ -125,6 +125,20 @@ def test_paired_mode_call_category(api, oracle_lib):
     oidx.free()
 
 
+def test_many_categories_paired(api, oracle_lib):
+    """more than 8 categories: the general row-log path and the array-free model+call kernel (call_category is C-way)"""
+    r = util.rng(17)
+    gs = [util.random_seq(r, 2500) for _ in range(20)]
+    cats = ["cat%d" % i for i in range(11)] + ["human"]
+    b2c = [i % 12 for i in range(20)]
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], b2c, cats, fill_seed=2, fill=0.03)
+    m1 = util.sample_reads(r, gs, 250, (80, 300), sub_rate=0.01)
+    m2 = util.sample_reads(r, gs, 250, (80, 300), sub_rate=0.01)
+    gpu, _ = check(api, oracle_lib, oidx, m1, m2)
+    assert len(np.unique(gpu["call"])) > 5
+    oidx.free()
+
+
 def test_other_k_w(api, oracle_lib):
     r = util.rng(4)
     for k, w in ((15, 25), (27, 31), (4, 8), (19, 19), (11, 41)):
