@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--workload", default="39g", choices=sorted(WORKLOADS))
     ap.add_argument("--reads-per-step", type=int, default=0, help="per GPU; default from the workload")
     ap.add_argument("--read-len", type=int, default=0)
+    ap.add_argument("--read-len-max", type=int, default=0, help="log-uniform lengths in [read-len, read-len-max] (BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -106,7 +107,8 @@ def main():
     index.synth_plant(genomes, B, wl["genome_len"], list(range(B)))
     # weak scaling: rank r classifies global reads [r*n, (r+1)*n) of one seeded read set (charon_amd/shard.py)
     lo, hi = (0, n_reads) if rows_mode else shard.shard_range(n_reads * world, rank, world)
-    reads = api.synth_reads(local, 42, genomes, B, wl["genome_len"], hi - lo, L, L, 0.05, 0.10, 40.0, first_read_id=lo)
+    Lmax = max(L, args.read_len_max)
+    reads = api.synth_reads(local, 42, genomes, B, wl["genome_len"], hi - lo, L, Lmax, 0.05, 0.10, 40.0, first_read_id=lo)
     stream = api.Stream(index, n_reads, reads.n_bases, profile=True)
     stream.set_model(api.default_model(2, 0))
     setup_s = time.time() - t_setup
@@ -215,7 +217,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": wl["desc"], "reads_per_step_per_gpu": n_reads, "read_len": L, "index_bytes": S * ((B + 63) // 64) * 8,
+            "config": {"workload": wl["desc"], "reads_per_step_per_gpu": n_reads, "read_len": L, "read_len_max": Lmax, "bases_per_step_per_gpu": int(reads.n_bases), "index_bytes": S * ((B + 63) // 64) * 8,
                        "sharding": ("index rows sharded over ranks, same batch on every rank, one sum all-reduce of probe words per batch" if rows_mode else
                                     "reads sharded over ranks, full index replica per GPU, no data-path collective"),
                        "mean_minimisers_per_read": total_min / n_reads, "borderline_reads": int(flags.sum()),

@@ -572,6 +572,8 @@ struct K3Args {
     uint8_t *call, *conf, *flags;
     const float *data;            // all KDE datasets back to back
     const uint32_t *tab;          // [4][C]: pos_off, pos_n, neg_off, neg_n per category
+    ulonglong2 *memo;             // direct-mapped cache (category, num_hashes, unique) -> probability; may be null
+    uint32_t memo_mask;
     uint32_t n_reads, C;
     float h_pos, h_neg, log_rate, rate;
     float min_quality, min_compression, cpt, lo_thr, min_pd, min_prd;
@@ -595,7 +597,7 @@ __device__ __forceinline__ float kde_prob_dev(const float *data, uint32_t n, flo
 }
 
 // Model::prob (include/classify_stats.hpp:370-389) of category c for a read with `uq` unique hits out of `nh` minimisers
-__device__ __forceinline__ double model_prob_dev(const K3Args &a, uint32_t c, uint32_t uq, uint32_t nh) {
+__device__ __forceinline__ double model_prob_compute(const K3Args &a, uint32_t c, uint32_t uq, uint32_t nh) {
     const float x = (float)uq / (float)nh;  // unique proportion (include/read_entry.hpp:140-150)
     float p_err;
     if (x != x) p_err = x;
@@ -606,6 +608,21 @@ __device__ __forceinline__ double model_prob_dev(const K3Args &a, uint32_t c, ui
     if (x == 1.0f) p_pos = 1.0f;
     const float total = p_err + p_pos + p_neg;
     return (double)(p_pos / total);  // probabilities_ starts at 1 and is multiplied once (:56,277)
+}
+// The probability is a pure function of (c, uq, nh) for a fixed model, and a batch holds few distinct triples (reads of
+// similar length), so it is memoised in a persistent direct-mapped table.  An entry is {check, prob} with
+// check = ~(key ^ bits(prob)): a torn, stale or empty (all-zero) entry fails the check and is simply recomputed, so no
+// ordering between writers and readers is needed; racing writers store identical values.
+__device__ __forceinline__ double model_prob_dev(const K3Args &a, uint32_t c, uint32_t uq, uint32_t nh) {
+    if (!a.memo || nh >= (1u << 28) || uq >= (1u << 28)) return model_prob_compute(a, c, uq, nh);
+    const uint64_t key = ((uint64_t)c << 56) | ((uint64_t)nh << 28) | uq;
+    ulonglong2 *slot = a.memo + (mix64(key) & a.memo_mask);
+    const ulonglong2 e = *slot;
+    if (e.x == ~(key ^ e.y)) return __longlong_as_double((long long)e.y);
+    const double p = model_prob_compute(a, c, uq, nh);
+    const uint64_t bits = (uint64_t)__double_as_longlong(p);
+    *slot = make_ulonglong2(~(key ^ bits), bits);
+    return p;
 }
 
 __global__ __launch_bounds__(256) void k_model_call(const K3Args a) {
@@ -892,6 +909,7 @@ struct chn_stream {
     // staging of host batches (large arrays; reused by the next batch in stream order)
     DevBuf d_bases, d_nmask, d_off1, d_off2;
     DevBuf d_order, d_hist, d_rows, d_rowown, d_wbase, d_wcount, d_model;
+    DevBuf d_memo;                    // k_model_call memo table (cleared whenever the model changes)
     DevBuf d_list, d_cbase;           // row-sharded mode: minimiser value log, compact entry offsets
     uint64_t shard_entries = 0;
     bool shard_open = false;
@@ -1108,7 +1126,7 @@ extern "C" int chn_stream_destroy(chn_stream *s) {
                           &sl.d_len1, &sl.d_len2, &sl.d_mq, &sl.d_comp};
         for (DevBuf *b : bufs) b->release();
     }
-    DevBuf *bufs[] = {&s->d_bases, &s->d_nmask, &s->d_off1, &s->d_off2, &s->d_order, &s->d_hist, &s->d_rows, &s->d_rowown, &s->d_wbase, &s->d_wcount, &s->d_model, &s->d_list, &s->d_cbase};
+    DevBuf *bufs[] = {&s->d_bases, &s->d_nmask, &s->d_off1, &s->d_off2, &s->d_order, &s->d_hist, &s->d_rows, &s->d_rowown, &s->d_wbase, &s->d_wcount, &s->d_model, &s->d_list, &s->d_cbase, &s->d_memo};
     for (DevBuf *b : bufs) b->release();
     delete s;
     return CHN_OK;
@@ -1156,6 +1174,10 @@ extern "C" int chn_model_set(chn_stream *s, const chn_model *m) {
     if (rc) return rc;
     HIPCHK(hipMemcpy(s->d_model.p, tab.data(), tab_bytes, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(static_cast<char *>(s->d_model.p) + tab_bytes, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
+    const uint32_t memo_entries = 1u << 21;  // 32 MiB
+    if ((rc = s->d_memo.ensure((size_t)memo_entries * 16))) return rc;
+    HIPCHK(hipMemset(s->d_memo.p, 0, (size_t)memo_entries * 16));
+    k.memo = s->d_memo.as<ulonglong2>(); k.memo_mask = memo_entries - 1;
     k.tab = s->d_model.as<uint32_t>();
     k.data = reinterpret_cast<const float *>(static_cast<char *>(s->d_model.p) + tab_bytes);
     k.C = C; k.h_pos = M.h_pos; k.h_neg = M.h_neg; k.rate = M.rate; k.log_rate = std::log(M.rate);

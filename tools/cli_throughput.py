@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""End-to-end throughput of the drop-in CLI (charon_amd/bin/charon dehost) on a synthetic FASTQ file.
+
+Builds a 2-category index file with the oracle's writer (test infrastructure used only to FABRICATE the input file),
+writes N synthetic 5 kb reads as FASTQ, then times the CLI at several -t values.  The CLI is expected to be bound by the
+host-side columns of the reference (per-read gzip ratio, FASTQ parsing, TSV printing), not by the GPU.
+usage: python tools/cli_throughput.py [n_reads] [workdir]
+"""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle as po  # noqa: E402
+from tests import util  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
+    work = sys.argv[2] if len(sys.argv) > 2 else "/tmp/charon_cli_bench"
+    os.makedirs(work, exist_ok=True)
+    r = util.rng(1)
+    gs = [util.random_seq(r, 2_000_000), util.random_seq(r, 2_000_000)]
+    t0 = time.time()
+    idx = util.build_oracle_index(po, [[gs[0]], [gs[1]]], [0, 1], ["microbial", "human"])
+    idx.compress()
+    idx.store(os.path.join(work, "bench.idx"))
+    print("index: S=%d rows, built+stored in %.1fs" % (idx.bin_size, time.time() - t0), flush=True)
+    fq = os.path.join(work, "reads.fastq")
+    t0 = time.time()
+    with open(fq, "wb") as f:
+        qual = b"I" * 5000
+        for i in range(n):
+            g = gs[i & 1]
+            s = int(r.integers(0, len(g) - 5000))
+            f.write(b"@r%d\n%s\n+\n%s\n" % (i, util.mutate(r, g[s:s + 5000], 0.05), qual))
+    print("fastq: %d reads, %.2f GB, written in %.1fs" % (n, os.path.getsize(fq) / 1e9, time.time() - t0), flush=True)
+    exe = os.path.join(ROOT, "charon_amd", "bin", "charon")
+    for t in (1, 16, 64):
+        t0 = time.time()
+        p = subprocess.run([exe, "dehost", "--db", os.path.join(work, "bench.idx"), "-t", str(t), "--log", os.path.join(work, "c.log"), fq],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        dt = time.time() - t0
+        rows = p.stdout.count(b"\n")
+        cls = sum(1 for line in p.stdout.split(b"\n") if line.startswith(b"C\t"))
+        print("charon dehost -t %d: rc=%d rows=%d classified=%d  %.2fs  -> %.0f reads/s" % (t, p.returncode, rows, cls, dt, n / dt), flush=True)
+        if p.returncode:
+            print(p.stderr.decode()[-500:])
+
+
+if __name__ == "__main__":
+    main()
