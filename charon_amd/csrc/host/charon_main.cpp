@@ -16,6 +16,10 @@
 #include <algorithm>
 #include <cerrno>
 #include <climits>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -351,46 +355,126 @@ public:
 };
 
 // ---------------------------------------------------------------------------------------------------
-// FASTA / FASTQ streaming reader (seqan3::sequence_file_input<my_traits> semantics, include/utils.hpp:17-19):
-// format by extension, optional .gz, dna5 alphabet (IUPAC -> N, lower case accepted, anything else is an error)
+// FASTA / FASTQ block reader (seqan3::sequence_file_input<my_traits> semantics, include/utils.hpp:17-19): format by
+// extension, optional .gz, dna5 alphabet (IUPAC -> N, lower case accepted, anything else is a parse error).
+// A block is a large slab of the (inflated) file holding whole records; records are views into the slab (multi-line
+// sequences are compacted in place), so nothing is copied per record and blocks can be parsed on a reader thread while
+// the previous block is packed / compressed / classified.
 // ---------------------------------------------------------------------------------------------------
-struct Record { std::string id, seq, qual; };
+struct RecView {
+    const char *id = nullptr, *seq = nullptr, *qual = nullptr;
+    uint32_t id_len = 0, seq_len = 0, qual_len = 0;
+};
+struct RawBlock {
+    std::vector<char> buf;
+    std::vector<RecView> recs;
+};
 
-class FastxReader {
+class BlockReader {
     gzFile f_ = nullptr;
-    bool fastq_ = false;
-    std::vector<char> buf_;
-    size_t pos_ = 0, len_ = 0;
-    bool eof_ = false;
-    std::string pending_;  // header line read ahead (FASTA)
-    bool have_pending_ = false;
+    bool fastq_ = false, eof_ = false;
+    std::vector<char> carry_;
+    std::string path_;
 
-    bool fill() {
-        if (eof_) return false;
-        int n = gzread(f_, buf_.data(), (unsigned)buf_.size());
-        if (n <= 0) { eof_ = true; len_ = pos_ = 0; return false; }
-        len_ = (size_t)n; pos_ = 0;
-        return true;
-    }
-    bool getline(std::string &line) {
-        line.clear();
-        bool got = false;
+    static const char *find_eol(const char *p, const char *end) { return static_cast<const char *>(std::memchr(p, '\n', (size_t)(end - p))); }
+
+    // Parse one record starting at p (non-destructively first).  Returns the position after the record, or nullptr if the
+    // data in [p, end) does not hold the whole record yet.
+    char *parse_fastq(char *p, char *end, RecView &r) {
+        while (p < end && (*p == '\n' || *p == '\r')) ++p;  // blank lines between records
+        if (p >= end) return nullptr;
+        if (*p != '@') throw std::runtime_error("FASTQ parse error in " + path_ + ": record does not start with '@'");
+        const char *e0 = find_eol(p, end);
+        if (!e0) return nullptr;
+        // pass 1: locate the line structure
+        struct Span { char *b; uint32_t n; };
+        Span seq_first{nullptr, 0}; bool multi = false;
+        uint64_t seq_len = 0;
+        char *q = const_cast<char *>(e0) + 1, *plus = nullptr;
         for (;;) {
-            if (pos_ >= len_ && !fill()) break;
-            got = true;
-            const char *b = buf_.data() + pos_;
-            const char *nl = static_cast<const char *>(std::memchr(b, '\n', len_ - pos_));
-            if (nl) { line.append(b, nl - b); pos_ += (size_t)(nl - b) + 1; break; }
-            line.append(b, len_ - pos_);
-            pos_ = len_;
+            if (q >= end) { if (!eof_) return nullptr; throw std::runtime_error("FASTQ parse error in " + path_ + ": unexpected end of file"); }
+            const char *e = find_eol(q, end);
+            if (!e) { if (!eof_) return nullptr; e = end; }
+            uint32_t n = (uint32_t)(e - q);
+            if (n && q[n - 1] == '\r') --n;
+            if (n && q[0] == '+') { plus = q; q = (e < end) ? const_cast<char *>(e) + 1 : end; break; }
+            if (!seq_first.b) seq_first = Span{q, n}; else if (n) multi = true;
+            seq_len += n;
+            q = (e < end) ? const_cast<char *>(e) + 1 : end;
         }
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        return got;
+        (void)plus;
+        char *qual_begin = q;
+        uint64_t qual_len = 0; bool qmulti = false; bool first_q = true;
+        while (qual_len < seq_len) {
+            if (q >= end) { if (!eof_) return nullptr; throw std::runtime_error("FASTQ parse error in " + path_ + ": qualities shorter than sequence"); }
+            const char *e = find_eol(q, end);
+            if (!e) { if (!eof_) return nullptr; e = end; }
+            uint32_t n = (uint32_t)(e - q);
+            if (n && q[n - 1] == '\r') --n;
+            if (!first_q && n) qmulti = true;
+            first_q = false;
+            qual_len += n;
+            q = (e < end) ? const_cast<char *>(e) + 1 : end;
+        }
+        if (seq_len == 0 && q < end && *q != '@') {  // zero-length read: its (empty) quality line
+            const char *e = find_eol(q, end);
+            if (e && (e == q || (e == q + 1 && *q == '\r'))) q = const_cast<char *>(e) + 1;
+        }
+        // pass 2: views (compacting multi-line records in place)
+        uint32_t idn = (uint32_t)(e0 - p - 1);
+        if (idn && p[idn] == '\r') --idn;
+        r.id = p + 1; r.id_len = idn;
+        auto compact = [&](char *from, uint64_t want, bool is_multi) -> const char * {
+            if (!is_multi) return from;
+            char *dst = from, *src = from;
+            uint64_t got = 0;
+            while (got < want) {
+                const char *e = find_eol(src, end);
+                if (!e) e = end;
+                uint32_t n = (uint32_t)(e - src);
+                if (n && src[n - 1] == '\r') --n;
+                if (dst != src) std::memmove(dst, src, n);
+                dst += n; got += n;
+                src = (e < end) ? const_cast<char *>(e) + 1 : end;
+            }
+            return from;
+        };
+        r.seq = seq_first.b ? compact(seq_first.b, seq_len, multi) : p; r.seq_len = (uint32_t)seq_len;
+        r.qual = compact(qual_begin, qual_len, qmulti); r.qual_len = (uint32_t)qual_len;
+        if (seq_len > 0xFFFFFFFFull) throw std::runtime_error("read longer than 2^32 bases");
+        return q;
     }
-    static bool valid_dna(char c) { return c && std::strchr("ACGTUNRYSWKMBDHVacgtunryswkmbdhv", c) != nullptr; }
+    char *parse_fasta(char *p, char *end, RecView &r) {
+        while (p < end && (*p == '\n' || *p == '\r')) ++p;
+        if (p >= end) return nullptr;
+        if (*p != '>' && *p != ';') throw std::runtime_error("FASTA parse error in " + path_ + ": record does not start with '>'");
+        const char *e0 = find_eol(p, end);
+        if (!e0) { if (!eof_) return nullptr; e0 = end; }
+        // the record ends at the next line that starts with '>' / ';', or at end of file
+        char *q = (e0 < end) ? const_cast<char *>(e0) + 1 : end;
+        char *rec_end = nullptr;
+        for (char *l = q;;) {
+            if (l >= end) { if (!eof_) return nullptr; rec_end = end; break; }
+            if (*l == '>' || *l == ';') { rec_end = l; break; }
+            const char *e = find_eol(l, end);
+            if (!e) { if (!eof_) return nullptr; rec_end = end; break; }
+            l = const_cast<char *>(e) + 1;
+        }
+        uint32_t idn = (uint32_t)(e0 - p - 1);
+        if (idn && p[idn] == '\r') --idn;
+        r.id = p + 1; r.id_len = idn;
+        char *dst = q;
+        for (char *c = q; c < rec_end; ++c) {  // seqan3 skips blanks and digits inside FASTA sequence lines
+            const char ch = *c;
+            if (ch == '\n' || ch == '\r' || ch == ' ' || ch == '\t' || (ch >= '0' && ch <= '9')) continue;
+            *dst++ = ch;
+        }
+        r.seq = q; r.seq_len = (uint32_t)(dst - q); r.qual = nullptr; r.qual_len = 0;
+        return rec_end;
+    }
 
 public:
-    explicit FastxReader(const std::string &path) : buf_(1 << 20) {
+    explicit BlockReader(const std::string &path) : path_(path) {
         std::string p = path;
         if (ends_with(p, ".gz")) p.resize(p.size() - 3);
         if (ends_with(p, ".bz2")) throw std::runtime_error("bz2 input is not supported by this build: " + path);
@@ -402,39 +486,51 @@ public:
         if (!f_) throw std::runtime_error("cannot open " + path);
         gzbuffer(f_, 1 << 20);
     }
-    ~FastxReader() { if (f_) gzclose(f_); }
-    FastxReader(const FastxReader &) = delete;
-    FastxReader &operator=(const FastxReader &) = delete;
+    ~BlockReader() { if (f_) gzclose(f_); }
+    BlockReader(const BlockReader &) = delete;
+    BlockReader &operator=(const BlockReader &) = delete;
 
-    bool next(Record &r) {
-        r.id.clear(); r.seq.clear(); r.qual.clear();
-        std::string line;
-        if (fastq_) {
-            do { if (!getline(line)) return false; } while (line.empty());
-            if (line[0] != '@') throw std::runtime_error("FASTQ parse error: record does not start with '@'");
-            r.id = line.substr(1);
-            for (;;) {
-                if (!getline(line)) throw std::runtime_error("FASTQ parse error: unexpected end of file");
-                if (!line.empty() && line[0] == '+') break;
-                r.seq += line;
+    // Fill `blk` with up to max_recs whole records (reading about max_bytes of new data at a time).  Returns false when
+    // the file is exhausted and nothing was produced.
+    bool next(RawBlock &blk, size_t max_recs, size_t max_bytes) {
+        blk.recs.clear();
+        blk.buf.swap(carry_);
+        carry_.clear();
+        size_t parsed_to = 0;
+        for (;;) {
+            // (re)parsing only ever starts from scratch while no record has been produced, because producing a record may
+            // compact it in place
+            if (!eof_) {
+                const size_t old = blk.buf.size();
+                blk.buf.resize(old + max_bytes);
+                size_t got = 0;
+                while (got < max_bytes) {
+                    const int n = gzread(f_, blk.buf.data() + old + got, (unsigned)std::min<size_t>(max_bytes - got, 1u << 30));
+                    if (n <= 0) { eof_ = true; break; }
+                    got += (size_t)n;
+                }
+                blk.buf.resize(old + got);
             }
-            while (r.qual.size() < r.seq.size()) {
-                if (!getline(line)) throw std::runtime_error("FASTQ parse error: qualities shorter than sequence");
-                r.qual += line;
+            char *base = blk.buf.data(), *end = base + blk.buf.size(), *p = base;
+            while (blk.recs.size() < max_recs) {
+                RecView r;
+                char *nx = fastq_ ? parse_fastq(p, end, r) : parse_fasta(p, end, r);
+                if (!nx) break;
+                blk.recs.push_back(r);
+                p = nx;
             }
-        } else {
-            if (!have_pending_) {
-                do { if (!getline(pending_)) return false; } while (pending_.empty());
-                if (pending_[0] != '>' && pending_[0] != ';') throw std::runtime_error("FASTA parse error: record does not start with '>'");
-            }
-            r.id = pending_.substr(1);
-            have_pending_ = false;
-            while (getline(line)) {
-                if (!line.empty() && (line[0] == '>' || line[0] == ';')) { pending_ = line; have_pending_ = true; break; }
-                for (char c : line) if (!(c == ' ' || c == '\t' || (c >= '0' && c <= '9'))) r.seq.push_back(c);
-            }
+            parsed_to = (size_t)(p - base);
+            if (!blk.recs.empty() || eof_) break;
+            // not even one whole record yet: read more and parse again
         }
-        for (char c : r.seq) if (!valid_dna(c)) throw std::runtime_error(std::string("parse error: illegal character '") + c + "' in sequence of " + r.id);
+        // whatever was not consumed goes to the next block
+        if (parsed_to < blk.buf.size()) {
+            bool only_ws = true;
+            for (size_t i = parsed_to; i < blk.buf.size() && only_ws; ++i) only_ws = (blk.buf[i] == '\n' || blk.buf[i] == '\r');
+            if (!only_ws) carry_.assign(blk.buf.begin() + (long)parsed_to, blk.buf.end());
+        }
+        if (blk.recs.empty() && eof_ && carry_.empty()) return false;
+        if (blk.recs.empty() && eof_) throw std::runtime_error("parse error in " + path_ + ": trailing data is not a whole record");
         return true;
     }
 };
@@ -448,24 +544,45 @@ inline int dna_code(char c) {  // 0..3 = ACGT, 4 = N (seqan3 dna5: every other I
         default: return 4;
     }
 }
+struct CodeTable {  // 0..3 ACGT, 4 N (other IUPAC letters), 255 illegal
+    uint8_t t[256];
+    CodeTable() {
+        std::memset(t, 255, sizeof t);
+        for (const char *c = "NRYSWKMBDHVnryswkmbdhv"; *c; ++c) t[(unsigned char)*c] = 4;
+        for (const char *c = "ACGTUacgtu"; *c; ++c) t[(unsigned char)*c] = (uint8_t)dna_code(*c);
+    }
+};
+const CodeTable g_codes;
 
-// get_compression_ratio (src/utils.cpp:114-124) of sequence_to_string(seq) (upper-case dna5 letters, :105-112)
-float compression_ratio(const std::string &s1, const std::string &s2) {
-    std::string up;
-    up.reserve(s1.size() + s2.size());
-    for (char c : s1) up.push_back("ACGTN"[dna_code(c)]);
-    for (char c : s2) up.push_back("ACGTN"[dna_code(c)]);
+// get_compression_ratio (src/utils.cpp:114-124) of sequence_to_string(seq) (upper-case dna5 letters, :105-112).
+// One z_stream per thread, deflateReset between reads (same output as a fresh deflateInit2, without its allocations).
+struct Deflater {
     z_stream zs;
-    std::memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
-    std::vector<unsigned char> out(deflateBound(&zs, (uLong)up.size()) + 64);
-    zs.next_in = (Bytef *)up.data(); zs.avail_in = (uInt)up.size();
-    zs.next_out = out.data(); zs.avail_out = (uInt)out.size();
-    deflate(&zs, Z_FINISH);
-    const size_t compressed = out.size() - zs.avail_out;
-    deflateEnd(&zs);
-    return static_cast<float>(static_cast<double>(compressed) / static_cast<double>(up.size()));
-}
+    bool init = false;
+    std::vector<unsigned char> out;
+    std::string up;
+    ~Deflater() { if (init) deflateEnd(&zs); }
+    float ratio(const RecView &a, const RecView *b) {
+        up.clear();
+        up.reserve((size_t)a.seq_len + (b ? b->seq_len : 0));
+        for (uint32_t i = 0; i < a.seq_len; ++i) up.push_back("ACGTN"[g_codes.t[(unsigned char)a.seq[i]] & 7]);
+        if (b) for (uint32_t i = 0; i < b->seq_len; ++i) up.push_back("ACGTN"[g_codes.t[(unsigned char)b->seq[i]] & 7]);
+        if (!init) {
+            std::memset(&zs, 0, sizeof zs);
+            if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
+            init = true;
+        } else {
+            deflateReset(&zs);
+        }
+        const size_t bound = deflateBound(&zs, (uLong)up.size()) + 64;
+        if (out.size() < bound) out.resize(bound);
+        zs.next_in = (Bytef *)up.data(); zs.avail_in = (uInt)up.size();
+        zs.next_out = out.data(); zs.avail_out = (uInt)out.size();
+        deflate(&zs, Z_FINISH);
+        const size_t compressed = out.size() - zs.avail_out;
+        return static_cast<float>(static_cast<double>(compressed) / static_cast<double>(up.size()));
+    }
+};
 
 // ---------------------------------------------------------------------------------------------------
 // per-read entry as the host sees it (ReadEntry, include/read_entry.hpp:16-64, minus the bit rows)
@@ -478,6 +595,8 @@ struct Entry {
     std::vector<double> prob;
     uint8_t call = 255, conf = 0;
     uint32_t model_version = 0;  // version of the KDE models the device used for prob/call/conf
+    std::string row;             // TSV row formatted (in parallel) for model_version; empty if not formatted yet
+    uint32_t row_version = 0;
 };
 
 // StatsModel training side (include/classify_stats.hpp:34-114,395-584); the probability/call itself runs on the GPU
@@ -536,6 +655,10 @@ struct Training {
     }
 };
 
+struct IndexMeta;
+struct Entry;
+void format_row(const IndexMeta &meta, const Entry &e, std::string &out);
+
 #define CHN_CHECK(call)                                                                              \
     do {                                                                                             \
         int _rc = (call);                                                                            \
@@ -591,21 +714,13 @@ class Result {
             for (size_t i = 0; i < n; ++i) {
                 Entry &e = *es[b + i];
                 e.prob.assign(prob.begin() + i * C, prob.begin() + (i + 1) * C);
-                e.call = call[i]; e.conf = conf[i]; e.model_version = training_.version;
+                e.call = call[i]; e.conf = conf[i]; e.model_version = training_.version; e.row.clear();
             }
         }
     }
-    void print(const Entry &e) {  // print_assignment_result, include/read_entry.hpp:322-337
-        out_ << (e.call == 255 ? "U" : "C") << "\t";
-        out_.precision(6);
-        out_ << e.read_id << "\t" << meta_.category_name(e.call) << "\t" << e.length << "\t" << e.num_hashes << "\t" << e.mean_quality << "\t"
-             << +e.conf << "\t" << e.compression << "\t";
-        for (size_t i = 0; i < meta_.categories.size(); ++i) {
-            const float prop = static_cast<float>(e.counts[i]) / static_cast<float>(e.num_hashes);      // get_proportions :140-150
-            const float uprop = static_cast<float>(e.unique[i]) / static_cast<float>(e.num_hashes);
-            out_ << meta_.categories[i] << ":" << e.counts[i] << ":" << prop << ":" << uprop << ":" << e.prob[i] << " ";
-        }
-        out_ << "\n";
+    void print(Entry &e) {  // print_assignment_result, include/read_entry.hpp:322-337
+        if (e.row.empty() || e.row_version != e.model_version) { format_row(meta_, e, e.row); e.row_version = e.model_version; }
+        out_.write(e.row.data(), (std::streamsize)e.row.size());
     }
     void classify_read(Entry &e) {  // include/result.hpp:97-116
         if (e.model_version != training_.version) { std::vector<Entry *> one(1, &e); reclassify(one); }
@@ -656,51 +771,132 @@ public:
 // batching: pack reads into the 2-bit layout of include/charon_hip.h
 // ---------------------------------------------------------------------------------------------------
 struct HostBatch {
-    std::vector<Record> r1, r2;
+    RawBlock blk1, blk2;               // records of this batch (views into the blocks' slabs)
+    std::vector<std::vector<char>> extra;  // further slabs of mate records when one block did not hold enough of them
+    std::vector<uint32_t> keep;        // indices of the records that are classified (zero-length reads are skipped)
     std::vector<uint32_t> bases, nmask, len1, len2;
     std::vector<uint64_t> off1, off2;
     std::vector<float> mq, comp;
     bool any_n = false;
     uint64_t n_bases = 0;
 
-    void clear() { r1.clear(); r2.clear(); }
     static uint64_t pad64(uint64_t x) { return (x + 63) & ~63ULL; }
-    void put(const std::string &s, uint64_t off) {
-        for (size_t i = 0; i < s.size(); ++i) {
-            const int c = dna_code(s[i]);
-            const uint64_t j = off + i;
-            if (c == 4) { nmask[j >> 5] |= 1u << (j & 31); any_n = true; }
-            else bases[j >> 4] |= (uint32_t)c << (2 * (j & 15));
+    // returns false on an illegal character
+    bool put(const RecView &r, uint64_t off, bool &saw_n) {
+        uint32_t *bw = bases.data() + (off >> 4);
+        uint32_t *nw = nmask.data() + (off >> 5);
+        const unsigned char *sq = reinterpret_cast<const unsigned char *>(r.seq);
+        bool ok = true;
+        for (uint32_t i = 0; i < r.seq_len; i += 16) {
+            uint32_t w = 0, nb = 0;
+            const uint32_t m = std::min<uint32_t>(16, r.seq_len - i);
+            for (uint32_t j = 0; j < m; ++j) {
+                const uint8_t c = g_codes.t[sq[i + j]];
+                if (c < 4) w |= (uint32_t)c << (2 * j);
+                else if (c == 4) nb |= 1u << j;
+                else ok = false;
+            }
+            bw[i >> 4] = w;
+            if (nb) { nw[i >> 5] |= nb << (i & 16); saw_n = true; }
         }
+        return ok;
     }
-    void pack(bool paired, int threads) {
-        const size_t n = r1.size();
+    // layout + parallel packing, mean quality and gzip ratio of the records in blk1 (/blk2)
+    void pack(bool paired, int threads, bool skip_compression) {
+        const size_t nrec = blk1.recs.size();
+        keep.clear();
+        for (size_t i = 0; i < nrec; ++i) {
+            const uint64_t L = (uint64_t)blk1.recs[i].seq_len + (paired ? blk2.recs[i].seq_len : 0);
+            if (L == 0) { g_log.warn("Ignoring read " + std::string(blk1.recs[i].id, blk1.recs[i].id_len) + " as has zero length!"); continue; }  // src/dehost_main.cpp:351-354
+            if (L > std::numeric_limits<uint32_t>::max()) { g_log.warn("Ignoring read as too long!"); continue; }
+            keep.push_back((uint32_t)i);
+        }
+        const size_t n = keep.size();
         off1.assign(n, 0); len1.assign(n, 0); mq.assign(n, 0); comp.assign(n, 0);
         if (paired) { off2.assign(n, 0); len2.assign(n, 0); }
         uint64_t cur = 0;
         for (size_t i = 0; i < n; ++i) {
-            off1[i] = cur; len1[i] = (uint32_t)r1[i].seq.size(); cur += pad64(len1[i]);
-            if (paired) { off2[i] = cur; len2[i] = (uint32_t)r2[i].seq.size(); cur += pad64(len2[i]); }
+            const uint32_t k = keep[i];
+            off1[i] = cur; len1[i] = blk1.recs[k].seq_len; cur += pad64(len1[i]);
+            if (paired) { off2[i] = cur; len2[i] = blk2.recs[k].seq_len; cur += pad64(len2[i]); }
         }
         n_bases = std::max<uint64_t>(cur, 64);
-        bases.assign(n_bases / 16, 0); nmask.assign(n_bases / 32, 0); any_n = false;
-        for (size_t i = 0; i < n; ++i) { put(r1[i].seq, off1[i]); if (paired) put(r2[i].seq, off2[i]); }
-#pragma omp parallel for num_threads(threads) schedule(dynamic, 16)
-        for (long i = 0; i < (long)n; ++i) {
-            // mean quality (src/dehost_main.cpp:355-360 / :441-450): int sum of phred (char - 33) / count, as float
-            int sum = 0;
-            size_t cnt = r1[i].qual.size();
-            for (char c : r1[i].qual) sum += (int)c - 33;
-            if (paired) { cnt += r2[i].qual.size(); for (char c : r2[i].qual) sum += (int)c - 33; }
-            mq[i] = cnt ? static_cast<float>(sum) / static_cast<float>(cnt) : 0.0f;
-            if (len1[i] + (paired ? len2[i] : 0u) > 0) comp[i] = compression_ratio(r1[i].seq, paired ? r2[i].seq : std::string());
+        bases.assign(n_bases / 16, 0); nmask.assign(n_bases / 32, 0);
+        bool saw_n = false, bad = false;
+#pragma omp parallel num_threads(threads)
+        {
+            Deflater defl;
+            bool my_n = false, my_bad = false;
+#pragma omp for schedule(dynamic, 16)
+            for (long i = 0; i < (long)n; ++i) {
+                const RecView &a = blk1.recs[keep[i]];
+                const RecView *b = paired ? &blk2.recs[keep[i]] : nullptr;
+                if (!put(a, off1[i], my_n)) my_bad = true;
+                if (b && !put(*b, off2[i], my_n)) my_bad = true;
+                // mean quality (src/dehost_main.cpp:355-360 / :441-450): int sum of phred (char - 33) / count, as float
+                int sum = 0;
+                size_t cnt = a.qual_len;
+                for (uint32_t j = 0; j < a.qual_len; ++j) sum += (int)a.qual[j] - 33;
+                if (b) { cnt += b->qual_len; for (uint32_t j = 0; j < b->qual_len; ++j) sum += (int)b->qual[j] - 33; }
+                mq[i] = cnt ? static_cast<float>(sum) / static_cast<float>(cnt) : 0.0f;
+                if (!skip_compression && !my_bad) comp[i] = defl.ratio(a, b);
+            }
+#pragma omp critical(batch_flags)
+            { saw_n = saw_n || my_n; bad = bad || my_bad; }
         }
+        any_n = saw_n;
+        if (bad) throw std::runtime_error("parse error: illegal character in a sequence (only IUPAC nucleotide letters are accepted)");
     }
 };
 
-std::string first_token(const std::string &id) {  // split(id, " ")[0] (src/utils.cpp:9-20)
-    const size_t e = id.find(' ');
-    return e == std::string::npos ? id : id.substr(0, e);
+// bounded hand-over of parsed blocks from the reader thread
+struct BlockQueue {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::unique_ptr<HostBatch>> q;
+    bool done = false;
+    std::string error;
+    void push(std::unique_ptr<HostBatch> b) {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return q.size() < 2; });
+        q.push_back(std::move(b));
+        cv.notify_all();
+    }
+    void finish(const std::string &err) { std::lock_guard<std::mutex> lk(m); done = true; error = err; cv.notify_all(); }
+    std::unique_ptr<HostBatch> pop() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return !q.empty() || done; });
+        if (q.empty()) return nullptr;
+        std::unique_ptr<HostBatch> b = std::move(q.front());
+        q.pop_front();
+        cv.notify_all();
+        return b;
+    }
+};
+
+std::string first_token(const char *id, uint32_t n) {  // split(id, " ")[0] (src/utils.cpp:9-20)
+    const void *sp = std::memchr(id, ' ', n);
+    return std::string(id, sp ? (size_t)(static_cast<const char *>(sp) - id) : (size_t)n);
+}
+
+// print_assignment_result (include/read_entry.hpp:322-337).  `os << float/double` at precision(6) in the default
+// floatfield is printf("%g"); integers as %u.  Formatting rows with snprintf lets batches be formatted in parallel.
+void format_row(const IndexMeta &meta, const Entry &e, std::string &out) {
+    char buf[128];
+    out.clear();
+    out += (e.call == 255 ? "U\t" : "C\t");
+    out += e.read_id; out += '\t';
+    out += meta.category_name(e.call); out += '\t';
+    std::snprintf(buf, sizeof buf, "%u\t%u\t%g\t%d\t%g\t", e.length, e.num_hashes, (double)e.mean_quality, (int)e.conf, (double)e.compression);
+    out += buf;
+    for (size_t i = 0; i < meta.categories.size(); ++i) {
+        const float prop = static_cast<float>(e.counts[i]) / static_cast<float>(e.num_hashes);      // get_proportions :140-150
+        const float uprop = static_cast<float>(e.unique[i]) / static_cast<float>(e.num_hashes);
+        out += meta.categories[i];
+        std::snprintf(buf, sizeof buf, ":%u:%g:%g:%g ", e.counts[i], (double)prop, (double)uprop, e.prob[i]);
+        out += buf;
+    }
+    out += '\n';
 }
 
 int dehost_main(DehostArguments &opt) {
@@ -772,81 +968,127 @@ int dehost_main(DehostArguments &opt) {
     Result result(meta, opt, stream, model, std::cout);
     g_log.info("Dehosting file " + opt.read_file + (opt.is_paired ? " and " + opt.read_file2 : ""));
 
-    FastxReader in1(opt.read_file);
-    std::unique_ptr<FastxReader> in2;
-    if (opt.is_paired) in2.reset(new FastxReader(opt.read_file2));
     const size_t C = meta.categories.size();
-    HostBatch hb;
+    const bool skip_compression = std::getenv("CHARON_SKIP_COMPRESSION") != nullptr;  // NOT reference behaviour: prints 0
+    if (skip_compression) g_log.warn("CHARON_SKIP_COMPRESSION set: the compression column is 0 (differs from the reference)");
+
+    // reader thread: parses whole-record blocks while the previous batch is packed / compressed / classified / printed
+    BlockQueue queue;
+    std::thread reader([&]() {
+        try {
+            BlockReader in1(opt.read_file);
+            std::unique_ptr<BlockReader> in2;
+            if (opt.is_paired) in2.reset(new BlockReader(opt.read_file2));
+            const size_t max_bytes = (size_t)std::min<uint64_t>(256ULL << 20, std::max<uint64_t>(1 << 20, opt.batch_bases));
+            for (;;) {
+                std::unique_ptr<HostBatch> hb(new HostBatch());
+                // a batch may hold at most batch_bases padded bases: bound the record count by the byte budget as well
+                if (!in1.next(hb->blk1, opt.batch_reads, max_bytes)) break;
+                if (opt.is_paired) {
+                    // the second file is simply `take`n in step with the first (src/dehost_main.cpp:413-415)
+                    if (!in2->next(hb->blk2, hb->blk1.recs.size(), max_bytes)) break;
+                    while (hb->blk2.recs.size() < hb->blk1.recs.size()) {
+                        // the byte budget cut the mate block short: read further mate blocks until the counts agree
+                        RawBlock more;
+                        if (!in2->next(more, hb->blk1.recs.size() - hb->blk2.recs.size(), max_bytes)) break;
+                        // moving a vector keeps its heap buffer, so the views into `more.buf` stay valid
+                        hb->blk2.recs.insert(hb->blk2.recs.end(), more.recs.begin(), more.recs.end());
+                        hb->extra.emplace_back(std::move(more.buf));
+                    }
+                    if (hb->blk2.recs.size() < hb->blk1.recs.size()) hb->blk1.recs.resize(hb->blk2.recs.size());
+                }
+                queue.push(std::move(hb));
+            }
+            queue.finish("");
+        } catch (std::exception &e) {
+            queue.finish(e.what());
+        }
+    });
+
     std::vector<uint32_t> nh, cnt, unq;
     std::vector<double> prob;
     std::vector<uint8_t> call, conf, flags;
-    bool more = true, have_carry = false;
-    Record a, b;
-    while (more) {
-        hb.clear();
-        uint64_t bases = 0;
-        while (hb.r1.size() < opt.batch_reads) {
-            if (have_carry) {  // a read pair that did not fit the previous batch
-                have_carry = false;
-            } else {
-            if (!in1.next(a)) { more = false; break; }
+    std::vector<Entry> entries;
+    std::string failure;
+    try {
+        while (std::unique_ptr<HostBatch> hbp = queue.pop()) {
+            HostBatch &hb = *hbp;
+            const size_t nrec = hb.blk1.recs.size();
             if (opt.is_paired) {
-                if (!in2->next(b)) { more = false; break; }  // the second file is simply `take`n (src/dehost_main.cpp:413-415)
-                std::string id1 = a.id, id2 = b.id;
-                if (!id1.empty()) id1.erase(id1.size() - 1);
-                if (!id2.empty()) id2.erase(id2.size() - 1);
-                if (id1 != id2) {  // :423-430: prints to stdout and throws inside the OpenMP region -> terminate
-                    std::cout << id1 << " " << id2;
-                    std::cout.flush();
-                    std::fprintf(stderr, "terminate called after throwing an instance of 'std::runtime_error'\n  what():  Your pairs don't match for read ids.\n");
-                    std::abort();
+                for (size_t i = 0; i < nrec; ++i) {  // pair ids must agree after dropping the last character (:423-430)
+                    const RecView &a = hb.blk1.recs[i], &b = hb.blk2.recs[i];
+                    const uint32_t la = a.id_len ? a.id_len - 1 : 0, lb = b.id_len ? b.id_len - 1 : 0;
+                    if (la != lb || std::memcmp(a.id, b.id, la) != 0) {
+                        std::cout.flush();
+                        std::cout << std::string(a.id, la) << " " << std::string(b.id, lb);
+                        std::cout.flush();
+                        std::fprintf(stderr, "terminate called after throwing an instance of 'std::runtime_error'\n  what():  Your pairs don't match for read ids.\n");
+                        std::abort();
+                    }
                 }
             }
-            const uint64_t L = a.seq.size() + (opt.is_paired ? b.seq.size() : 0);
-            if (L == 0) { g_log.warn("Ignoring read " + a.id + " as has zero length!"); continue; }  // :351-354
-            if (L > std::numeric_limits<uint32_t>::max()) { g_log.warn("Ignoring read " + a.id + " as too long!"); continue; }
-            const uint64_t need = HostBatch::pad64(a.seq.size()) + (opt.is_paired ? HostBatch::pad64(b.seq.size()) : 0);
-            if (need > opt.batch_bases) throw std::runtime_error("read " + a.id + " is longer than CHARON_BATCH_BASES");
+            // split the block into GPU batches that respect the stream's capacity
+            size_t begin = 0;
+            while (begin < nrec) {
+                uint64_t bases = 0;
+                size_t endi = begin;
+                while (endi < nrec && endi - begin < opt.batch_reads) {
+                    const uint64_t need = HostBatch::pad64(hb.blk1.recs[endi].seq_len) + (opt.is_paired ? HostBatch::pad64(hb.blk2.recs[endi].seq_len) : 0);
+                    if (need > opt.batch_bases) throw std::runtime_error("a read is longer than CHARON_BATCH_BASES");
+                    if (bases + need > opt.batch_bases) break;
+                    bases += need; ++endi;
+                }
+                HostBatch sub;
+                sub.blk1.recs.assign(hb.blk1.recs.begin() + (long)begin, hb.blk1.recs.begin() + (long)endi);
+                if (opt.is_paired) sub.blk2.recs.assign(hb.blk2.recs.begin() + (long)begin, hb.blk2.recs.begin() + (long)endi);
+                begin = endi;
+                sub.pack(opt.is_paired, opt.threads, skip_compression);
+                const size_t n = sub.keep.size();
+                if (n == 0) continue;
+                result.ensure_device_model();
+                const uint32_t version = result.current_model_version();
+                chn_batch bt;
+                std::memset(&bt, 0, sizeof bt);
+                bt.struct_size = sizeof bt; bt.on_device = 0; bt.n_reads = n; bt.n_bases = sub.n_bases;
+                bt.bases2 = sub.bases.data(); bt.nmask = sub.any_n ? sub.nmask.data() : nullptr;
+                bt.seg1_offset = sub.off1.data(); bt.seg1_length = sub.len1.data();
+                bt.seg2_offset = opt.is_paired ? sub.off2.data() : nullptr; bt.seg2_length = opt.is_paired ? sub.len2.data() : nullptr;
+                bt.mean_quality = sub.mq.data(); bt.compression = sub.comp.data();
+                CHN_CHECK(chn_batch_submit(stream, &bt));
+                nh.resize(n); cnt.resize(n * C); unq.resize(n * C); prob.resize(n * C); call.resize(n); conf.resize(n); flags.resize(n);
+                chn_result rs;
+                std::memset(&rs, 0, sizeof rs);
+                rs.struct_size = sizeof rs; rs.on_device = 0;
+                rs.num_hashes = nh.data(); rs.counts = cnt.data(); rs.unique_counts = unq.data(); rs.probabilities = prob.data();
+                rs.call = call.data(); rs.confidence = conf.data(); rs.flags = flags.data();
+                CHN_CHECK(chn_batch_wait(stream, &rs));
+                // build the entries and format their rows in parallel ...
+                entries.assign(n, Entry());
+#pragma omp parallel for num_threads(opt.threads) schedule(static)
+                for (long i = 0; i < (long)n; ++i) {
+                    Entry &e = entries[i];
+                    const RecView &a = sub.blk1.recs[sub.keep[i]];
+                    e.read_id = first_token(a.id, a.id_len);
+                    e.length = sub.len1[i] + (opt.is_paired ? sub.len2[i] : 0u);
+                    e.num_hashes = nh[i]; e.mean_quality = sub.mq[i]; e.compression = sub.comp[i];
+                    e.counts.assign(cnt.begin() + i * C, cnt.begin() + (i + 1) * C);
+                    e.unique.assign(unq.begin() + i * C, unq.begin() + (i + 1) * C);
+                    e.prob.assign(prob.begin() + i * C, prob.begin() + (i + 1) * C);
+                    e.call = call[i]; e.conf = conf[i]; e.model_version = version; e.row_version = version;
+                    format_row(meta, e, e.row);
+                }
+                // ... then critical(add_read_to_results): serial, in input order (what the reference does at -t 1)
+                for (size_t i = 0; i < n; ++i) result.add_read(entries[i]);
             }
-            const uint64_t need = HostBatch::pad64(a.seq.size()) + (opt.is_paired ? HostBatch::pad64(b.seq.size()) : 0);
-            if (bases + need > opt.batch_bases) { have_carry = true; break; }
-            hb.r1.push_back(std::move(a));
-            if (opt.is_paired) hb.r2.push_back(std::move(b));
-            bases += need;
         }
-        const size_t n = hb.r1.size();
-        if (n == 0) continue;
-        hb.pack(opt.is_paired, opt.threads);
-        result.ensure_device_model();
-        const uint32_t version = result.current_model_version();
-        chn_batch bt;
-        std::memset(&bt, 0, sizeof bt);
-        bt.struct_size = sizeof bt; bt.on_device = 0; bt.n_reads = n; bt.n_bases = hb.n_bases;
-        bt.bases2 = hb.bases.data(); bt.nmask = hb.any_n ? hb.nmask.data() : nullptr;
-        bt.seg1_offset = hb.off1.data(); bt.seg1_length = hb.len1.data();
-        bt.seg2_offset = opt.is_paired ? hb.off2.data() : nullptr; bt.seg2_length = opt.is_paired ? hb.len2.data() : nullptr;
-        bt.mean_quality = hb.mq.data(); bt.compression = hb.comp.data();
-        CHN_CHECK(chn_batch_submit(stream, &bt));
-        nh.resize(n); cnt.resize(n * C); unq.resize(n * C); prob.resize(n * C); call.resize(n); conf.resize(n); flags.resize(n);
-        chn_result rs;
-        std::memset(&rs, 0, sizeof rs);
-        rs.struct_size = sizeof rs; rs.on_device = 0;
-        rs.num_hashes = nh.data(); rs.counts = cnt.data(); rs.unique_counts = unq.data(); rs.probabilities = prob.data();
-        rs.call = call.data(); rs.confidence = conf.data(); rs.flags = flags.data();
-        CHN_CHECK(chn_batch_wait(stream, &rs));
-        // critical(add_read_to_results): serial, in input order (what the reference does at -t 1)
-        for (size_t i = 0; i < n; ++i) {
-            Entry e;
-            e.read_id = first_token(hb.r1[i].id);
-            e.length = hb.len1[i] + (opt.is_paired ? hb.len2[i] : 0u);
-            e.num_hashes = nh[i]; e.mean_quality = hb.mq[i]; e.compression = hb.comp[i];
-            e.counts.assign(cnt.begin() + i * C, cnt.begin() + (i + 1) * C);
-            e.unique.assign(unq.begin() + i * C, unq.begin() + (i + 1) * C);
-            e.prob.assign(prob.begin() + i * C, prob.begin() + (i + 1) * C);
-            e.call = call[i]; e.conf = conf[i]; e.model_version = version;
-            result.add_read(e);
-        }
+        if (!queue.error.empty()) failure = queue.error;
+    } catch (std::exception &e) {
+        failure = e.what();
+        // drain so that the reader thread can finish
+        while (queue.pop()) {}
     }
+    reader.join();
+    if (!failure.empty()) { std::cout.flush(); throw std::runtime_error(failure); }
     result.complete();
     std::cout.flush();
     result.print_summary();

@@ -105,6 +105,43 @@ def test_cli_paired_fasta_and_thresholds(tmp_path, oracle_lib):
     oidx.free()
 
 
+def test_cli_reader_formats(tmp_path, oracle_lib):
+    """wrapped (multi-line) FASTA and FASTQ, CRLF line ends, blank lines, a zero-length read, lower case + IUPAC codes:
+    the block reader must see the same records as the oracle's reader"""
+    r = util.rng(33)
+    gs = [util.random_seq(r, 5000), util.random_seq(r, 5000)]
+    oidx = util.build_oracle_index(oracle_lib, [[gs[0]], [gs[1]]], [0, 1], ["host", "microbial"])
+    oidx.compress()
+    oidx.store(str(tmp_path / "f.idx"))
+    reads = util.sample_reads(r, gs, 120, (30, 900), sub_rate=0.02)
+    reads[3] = reads[3][:100].lower() + b"RYKMSWN" + reads[3][107:]
+    reads[9] = b""
+    wrap = lambda s, w: "\n".join(s[i:i + w] for i in range(0, len(s), w)) if s else ""
+    with open(tmp_path / "w.fastq", "w", newline="") as f:
+        for i, s in enumerate(reads):
+            q = "".join(chr(33 + int(x)) for x in r.integers(20, 41, len(s)))
+            eol = "\r\n" if i % 3 == 0 else "\n"
+            f.write(("@w%d desc" + eol + "%s" + eol + "+" + eol + "%s" + eol) % (i, wrap(s.decode(), 70).replace("\n", eol), wrap(q, 70).replace("\n", eol)))
+            if i % 7 == 0:
+                f.write(eol)
+    with open(tmp_path / "w.fa", "w") as f:
+        for i, s in enumerate(reads):
+            f.write(">w%d\n%s\n" % (i, wrap(s.decode(), 60)))
+    for name, extra in (("w.fastq", []), ("w.fa", ["--min_quality", "0"])):
+        mq = 0.0 if extra else 15.0
+        want = oidx.dehost_files(str(tmp_path / name), min_quality=mq)
+        for env in ({}, {"CHARON_BATCH_READS": "17"}):
+            rc, out, err = run_cli(["--db", str(tmp_path / "f.idx")] + extra + [str(tmp_path / name)], str(tmp_path), env)
+            assert rc == 0, err
+            assert_same_tsv(out, want)
+    # an illegal sequence character is a parse error (non-zero exit), as in seqan3
+    with open(tmp_path / "bad.fastq", "w") as f:
+        f.write("@x\nACGTXACGT\n+\nIIIIIIIII\n")
+    rc, out, err = run_cli(["--db", str(tmp_path / "f.idx"), str(tmp_path / "bad.fastq")], str(tmp_path))
+    assert rc != 0
+    oidx.free()
+
+
 def test_cli_errors(tmp_path):
     fq = os.path.join(G, "cfg1_reads.fastq.gz")
     rc, out, err = run_cli(["--db", os.path.join(G, "cfg1.idx"), "--threads", "256", fq], str(tmp_path))
