@@ -259,6 +259,7 @@ public:
     uint64_t ef_size = 0, ef_ones = 0, high_bits = 0;
     uint8_t ef_wl = 0;
     std::vector<uint64_t> low, high;
+    std::vector<uint64_t> bits_per_bin;  // filled by stream_rows: set bits per technical bin (self-check iv)
 
     explicit IndexFile(const std::string &path) : is_(path, std::ios::binary), path_(path) {
         if (!is_) throw std::runtime_error("cannot open index file " + path);
@@ -322,6 +323,7 @@ public:
         const IndexMeta &m = meta;
         const uint64_t W = m.bin_words, TB = m.technical_bins, S = m.bin_size;
         std::vector<uint64_t> block(block_rows * W);
+        bits_per_bin.assign(TB, 0);
         uint64_t row0 = 0, k = 0, hp = 0, prev = 0;
         bool first = true;
         const uint64_t tail_mask = (m.bins & 63) ? ~((1ULL << (m.bins & 63)) - 1) : 0ULL;  // technical bins >= B in the last word
@@ -344,6 +346,7 @@ public:
                 if (tail_mask && (wd % W) == W - 1 && ((1ULL << (pos & 63)) & tail_mask))
                     throw std::runtime_error("index has a set bit in a technical bin >= num_bins");
                 block[wd - row0 * W] |= 1ULL << (pos & 63);
+                bits_per_bin[(wd % W) * 64 + (pos & 63)] += 1;
                 prev = pos; first = false;
                 ++k; ++hp;
             }
@@ -899,6 +902,55 @@ void format_row(const IndexMeta &meta, const Entry &e, std::string &out) {
     out += '\n';
 }
 
+// loader self-check (v), SURVEY 8(c): if a reference FASTA recorded in the index (filepath_to_bin) is still readable, every
+// minimiser of it must be found in its bin.  This is the first-contact test for the third-party behaviour this build
+// only recalls (seqan3's hash_and_fit fastrange vs the older modulo variant, seeds, alphabet): a miss is reported loudly
+// in the log and on stderr, never guessed around.  Only the first 200 kb of at most 8 files are probed.
+void self_check_reference_files(const IndexMeta &meta, chn_stream *stream, const DehostArguments &opt) {
+    size_t checked = 0;
+    for (const auto &fb : meta.filepath_to_bin) {
+        if (checked >= 8) break;
+        if (!is_file(fb.first)) continue;
+        try {
+            BlockReader in(fb.first);
+            RawBlock blk;
+            if (!in.next(blk, 4, 1 << 20)) continue;
+            HostBatch hb;
+            hb.blk1.recs = blk.recs;
+            for (RecView &r : hb.blk1.recs) r.seq_len = std::min<uint32_t>(r.seq_len, 200000);
+            hb.pack(false, 1, true);
+            const size_t n = hb.keep.size();
+            if (n == 0 || n > opt.batch_reads || hb.n_bases > opt.batch_bases) continue;
+            chn_batch bt;
+            std::memset(&bt, 0, sizeof bt);
+            bt.struct_size = sizeof bt; bt.n_reads = n; bt.n_bases = hb.n_bases; bt.bases2 = hb.bases.data();
+            bt.nmask = hb.any_n ? hb.nmask.data() : nullptr; bt.seg1_offset = hb.off1.data(); bt.seg1_length = hb.len1.data();
+            CHN_CHECK(chn_batch_submit(stream, &bt));
+            const size_t C = meta.categories.size();
+            std::vector<uint32_t> nh(n), cnt(n * C), unq(n * C);
+            chn_result rs;
+            std::memset(&rs, 0, sizeof rs);
+            rs.struct_size = sizeof rs; rs.num_hashes = nh.data(); rs.counts = cnt.data(); rs.unique_counts = unq.data();
+            CHN_CHECK(chn_batch_wait(stream, &rs));
+            const uint8_t cat = meta.category_index(meta.bin_to_category.at(fb.second));
+            for (size_t i = 0; i < n; ++i) {
+                // counts_[cat] is the best bin of the category: it must be at least what the file's own bin holds = all of them
+                if (cnt[i * C + cat] != nh[i]) {
+                    const std::string msg = "self-check FAILED: only " + std::to_string(cnt[i * C + cat]) + " of " + std::to_string(nh[i]) +
+                                            " minimisers of " + fb.first + " are found in the index -- the hash / alphabet conventions of this build do not match the program that wrote the index";
+                    g_log.error(msg);
+                    std::fprintf(stderr, "charon: %s\n", msg.c_str());
+                    return;
+                }
+            }
+            ++checked;
+        } catch (std::exception &e) {
+            g_log.debug(std::string("self-check skipped for ") + fb.first + ": " + e.what());
+        }
+    }
+    if (checked) g_log.info("self-check: minimisers of " + std::to_string(checked) + " reference file(s) all found in their bins");
+}
+
 int dehost_main(DehostArguments &opt) {
     g_log.open(opt.log_file, opt.verbosity);
     if (!ends_with(opt.db, ".idx")) opt.db += ".idx";                 // src/dehost_main.cpp:489-491
@@ -949,6 +1001,17 @@ int dehost_main(DehostArguments &opt) {
     file.stream_rows(block_rows, [&](uint64_t row0, uint64_t nrows, const uint64_t *words) { CHN_CHECK(chn_index_upload_rows(index, row0, nrows, words)); });
     file.low.clear(); file.low.shrink_to_fit(); file.high.clear(); file.high.shrink_to_fit();
     g_log.info("Index loaded");
+    // loader self-check (iv), SURVEY 8(c): a bin that received n distinct values through h hash functions should have
+    // about S * (1 - exp(-h n / S)) set bits.  Reported, never fatal (hashes_per_bin counts are what `charon index` stored).
+    for (uint64_t b = 0; b < meta.bins; ++b) {
+        auto it = meta.hashes_per_bin.find((uint8_t)b);
+        if (it == meta.hashes_per_bin.end() || it->second == 0) continue;
+        const double expect = (double)meta.bin_size * (1.0 - std::exp(-(double)meta.hash_funs * (double)it->second / (double)meta.bin_size));
+        const double got = (double)file.bits_per_bin[b];
+        if (std::fabs(got - expect) > 0.02 * expect + 64)
+            g_log.warn("self-check: bin " + std::to_string(b) + " has " + std::to_string((uint64_t)got) + " set bits, expected about " +
+                       std::to_string((uint64_t)expect) + " for its " + std::to_string(it->second) + " hashes");
+    }
 
     chn_stream_cfg cfg;
     cfg.struct_size = sizeof cfg; cfg.flags = 0; cfg.max_reads = opt.batch_reads; cfg.max_bases = opt.batch_bases;
@@ -963,6 +1026,8 @@ int dehost_main(DehostArguments &opt) {
     model.min_proportion_difference = opt.min_proportion_difference; model.min_prob_difference = opt.min_prob_difference;
     model.min_hits = opt.min_hits;
     CHN_CHECK(chn_model_set(stream, &model));
+
+    self_check_reference_files(meta, stream, opt);
 
     std::ios::sync_with_stdio(false);
     Result result(meta, opt, stream, model, std::cout);

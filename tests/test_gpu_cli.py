@@ -52,6 +52,11 @@ def test_cli_golden_cfg1(tmp_path):
     assert rc == 0, err
     assert_same_tsv(out, open(os.path.join(G, "cfg1_expected.tsv")).read())
     assert out.split("\n")[0].split("\t")[1] == "r1"  # r0 is dropped (no --extract)
+    # loader self-check (v): the index records the reference FASTA paths; when they are readable their minimisers are probed
+    log = open(tmp_path / "charon.log").read()
+    if all(os.path.exists(p) for p in ("/root/repo/tests/golden/my.fasta", "/root/repo/tests/golden/cfg1_host.fasta")):
+        assert "self-check: minimisers of 2 reference file(s) all found" in log
+    assert "self-check FAILED" not in log and "self-check FAILED" not in err
     # small GPU batches, more host threads: identical rows
     rc, out2, err = run_cli(["--db", os.path.join(G, "cfg1.idx"), "-t", "4", fq], str(tmp_path), {"CHARON_BATCH_READS": "37"})
     assert rc == 0 and out2 == out
@@ -140,6 +145,24 @@ def test_cli_reader_formats(tmp_path, oracle_lib):
     rc, out, err = run_cli(["--db", str(tmp_path / "f.idx"), str(tmp_path / "bad.fastq")], str(tmp_path))
     assert rc != 0
     oidx.free()
+
+
+def test_cli_self_check_catches_foreign_index(tmp_path, oracle_lib):
+    """if the reference FASTA named in the index does not hash into its bin, the loader says so loudly (hard part H6)"""
+    r = util.rng(44)
+    for i in range(2):
+        with open(tmp_path / ("g%d.fa" % i), "w") as f:
+            f.write(">g%d\n%s\n" % (i, util.random_seq(r, 4000).decode()))
+    oidx = oracle_lib.Index.from_fasta([(str(tmp_path / "g0.fa"), "host"), (str(tmp_path / "g1.fa"), "other")], ["host", "other"])
+    oidx.store(str(tmp_path / "s.idx"))
+    oidx.free()
+    with open(tmp_path / "g0.fa", "w") as f:  # the file on disk no longer is what was indexed
+        f.write(">g0\n%s\n" % util.random_seq(r, 4000).decode())
+    with open(tmp_path / "q.fastq", "w") as f:
+        f.write("@a\n%s\n+\n%s\n" % ("ACGT" * 50, "I" * 200))
+    rc, out, err = run_cli(["--db", str(tmp_path / "s.idx"), str(tmp_path / "q.fastq")], str(tmp_path))
+    assert rc == 0 and "self-check FAILED" in err
+    assert "self-check FAILED" in open(tmp_path / "charon.log").read()
 
 
 def test_cli_errors(tmp_path):
