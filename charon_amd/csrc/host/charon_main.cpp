@@ -11,8 +11,9 @@
 //   * TSV row: include/read_entry.hpp:322-337
 // Host-side columns kept on the CPU as the survey prescribes: mean quality (src/dehost_main.cpp:355-360) and the
 // gzip compression ratio (src/utils.cpp:114-124, zlib, computed in an OpenMP loop overlapping nothing yet).
-// Not implemented: --extract output files (the flag still drives the training cache exactly as in
-// the reference), gamma/beta distributions (rejected like an unknown --dist), .bz2 input.
+// --extract writes <prefix>_<category>[_1|_2]<ext>.gz like src/dehost_main.cpp:515-536 / include/result.hpp:118-128 (plain gzip
+// members; record layout as seqan3's sequence_file_output, which is recalled, not verified).
+// Not implemented: gamma/beta distributions (rejected like an unknown --dist), .bz2 input.
 #include <algorithm>
 #include <cerrno>
 #include <climits>
@@ -101,6 +102,7 @@ struct DehostArguments {
     uint64_t batch_reads = 65536, batch_bases = 1ULL << 30;
     int device = 0;
     uint8_t min_hits = 0;  // StatsModel::min_hits_ is uninitialised in the reference; CHARON_MIN_HITS overrides
+    std::map<uint8_t, std::vector<std::string>> extract_category_to_file;  // include/dehost_arguments.hpp:20
 };
 
 struct ParseError : std::runtime_error { using std::runtime_error::runtime_error; };
@@ -599,6 +601,7 @@ struct Entry {
     uint8_t call = 255, conf = 0;
     uint32_t model_version = 0;  // version of the KDE models the device used for prob/call/conf
     std::string row;             // TSV row formatted (in parallel) for model_version; empty if not formatted yet
+    std::string rec_id, rec_seq, rec_qual, rec2_id, rec2_seq, rec2_qual;  // only kept when --extract is given
     uint32_t row_version = 0;
 };
 
@@ -682,6 +685,35 @@ class Result {
     uint64_t unclassified_ = 0;
     std::ostream &out_;
     bool dehost_;  // call_host (single-end) vs call_category (paired; src/dehost_main.cpp:470,475)
+    // extract_handles_ (include/result.hpp:44,80-85): one gz FASTA/FASTQ writer per requested category (two when paired)
+    struct ExtractFile { gzFile f; bool fastq; };
+    std::map<uint8_t, std::vector<ExtractFile>> extract_;
+
+    // seqan3::sequence_file_output record layout [3P-recall]: FASTQ "@id\nSEQ\n+\nQUAL\n"; FASTA ">id\n" + the sequence in
+    // lines of 80 letters.  The sequence is the record's dna5 content, i.e. upper case with every non-ACGT letter as N.
+    static void write_record(const ExtractFile &x, const std::string &id, const std::string &seq, const std::string &qual) {
+        std::string o;
+        o.reserve(id.size() + seq.size() * 2 + 16);
+        o += x.fastq ? '@' : '>';
+        o += id; o += '\n';
+        if (x.fastq) {
+            for (char c : seq) o += "ACGTN"[g_codes.t[(unsigned char)c] & 7];
+            o += "\n+\n"; o += qual; o += '\n';
+        } else {
+            for (size_t i = 0; i < seq.size(); ++i) {
+                o += "ACGTN"[g_codes.t[(unsigned char)seq[i]] & 7];
+                if ((i + 1) % 80 == 0 || i + 1 == seq.size()) o += '\n';
+            }
+            if (seq.empty()) o += '\n';
+        }
+        if (gzwrite(x.f, o.data(), (unsigned)o.size()) != (int)o.size()) throw std::runtime_error("write to extract file failed");
+    }
+    void extract(const Entry &e) {  // extract_read / extract_paired_read (include/result.hpp:118-128)
+        auto it = extract_.find(e.call);
+        if (it == extract_.end()) return;
+        write_record(it->second[0], e.rec_id, e.rec_seq, e.rec_qual);
+        if (it->second.size() > 1) write_record(it->second[1], e.rec2_id, e.rec2_seq, e.rec2_qual);
+    }
 
     void push_model_to_device() {
         const uint32_t C = (uint32_t)meta_.categories.size();
@@ -729,6 +761,7 @@ class Result {
         if (e.model_version != training_.version) { std::vector<Entry *> one(1, &e); reclassify(one); }
         print(e);
         if (e.call < 255) classified_counts_[e.call] += 1; else unclassified_ += 1;
+        if (!extract_.empty()) extract(e);  // add_read / classify_cache: extract right after classify_read (:131-136,186-195)
     }
     void classify_cache() {  // :181-198
         std::vector<Entry *> stale;
@@ -744,7 +777,20 @@ public:
           classified_counts_(meta.categories.size(), 0), out_(out), dehost_(!opt.is_paired) {
         // cached_reads_.reserve() sits inside the `if (opt.run_extract)` loop (include/result.hpp:80-85): capacity 0 otherwise
         if (opt.run_extract) cache_capacity_ = (size_t)opt.num_reads_to_fit * meta.categories.size() * 4;
+        for (const auto &kv : opt.extract_category_to_file)
+            for (const std::string &path : kv.second) {
+                std::string p = path;
+                if (ends_with(p, ".gz")) p.resize(p.size() - 3);
+                ExtractFile x;
+                x.fastq = ends_with(p, ".fastq") || ends_with(p, ".fq");
+                x.f = gzopen(path.c_str(), "wb");
+                if (!x.f) throw std::runtime_error("cannot create extract file " + path);
+                extract_[kv.first].push_back(x);
+            }
     }
+    ~Result() { for (auto &kv : extract_) for (ExtractFile &x : kv.second) if (x.f) gzclose(x.f); }
+    Result(const Result &) = delete;
+    Result &operator=(const Result &) = delete;
     uint32_t current_model_version() const { return training_.version; }
     void ensure_device_model() { if (device_model_version_ != training_.version) push_model_to_device(); }
 
@@ -975,7 +1021,27 @@ int dehost_main(DehostArguments &opt) {
         g_log.error("Cannot extract " + opt.category_to_extract + ", please chose one of [ all " + options + "]");
         return 1;  // the reference's callback drops this value: exit status stays 0 (src/dehost_main.cpp:311,513-514)
     }
-    if (opt.run_extract) g_log.warn("--extract: output files are not written by this build; the flag only drives the training cache");
+    if (opt.run_extract) {  // src/dehost_main.cpp:515-536
+        if (opt.prefix.empty()) opt.prefix = "charon";
+        std::vector<std::string> to_extract;
+        if (opt.category_to_extract == "all") to_extract = meta.categories; else to_extract.push_back(opt.category_to_extract);
+        // get_extension (src/utils.cpp:126-133): extension of the read file, looking through a trailing .gz
+        std::string base = opt.read_file;
+        const size_t slash = base.find_last_of('/');
+        if (slash != std::string::npos) base = base.substr(slash + 1);
+        auto ext_of = [](const std::string &f) { const size_t d = f.find_last_of('.'); return (d == std::string::npos || d == 0) ? std::string() : f.substr(d); };
+        std::string extension = ext_of(base);
+        if (extension == ".gz") extension = ext_of(base.substr(0, base.size() - 3));
+        for (const std::string &category : to_extract) {
+            const uint8_t ci = meta.category_index(category);
+            if (opt.is_paired) {
+                opt.extract_category_to_file[ci].push_back(opt.prefix + "_" + category + "_1" + extension + ".gz");
+                opt.extract_category_to_file[ci].push_back(opt.prefix + "_" + category + "_2" + extension + ".gz");
+            } else {
+                opt.extract_category_to_file[ci].push_back(opt.prefix + "_" + category + extension + ".gz");
+            }
+        }
+    }
     if (opt.dist != "gamma" && opt.dist != "beta" && opt.dist != "kde") {
         g_log.error("Supported distributions are [gamma , beta, kde]");
         return 1;
@@ -1141,6 +1207,13 @@ int dehost_main(DehostArguments &opt) {
                     e.prob.assign(prob.begin() + i * C, prob.begin() + (i + 1) * C);
                     e.call = call[i]; e.conf = conf[i]; e.model_version = version; e.row_version = version;
                     format_row(meta, e, e.row);
+                    if (opt.run_extract) {
+                        e.rec_id.assign(a.id, a.id_len); e.rec_seq.assign(a.seq, a.seq_len); e.rec_qual.assign(a.qual ? a.qual : "", a.qual_len);
+                        if (opt.is_paired) {
+                            const RecView &b = sub.blk2.recs[sub.keep[i]];
+                            e.rec2_id.assign(b.id, b.id_len); e.rec2_seq.assign(b.seq, b.seq_len); e.rec2_qual.assign(b.qual ? b.qual : "", b.qual_len);
+                        }
+                    }
                 }
                 // ... then critical(add_read_to_results): serial, in input order (what the reference does at -t 1)
                 for (size_t i = 0; i < n; ++i) result.add_read(entries[i]);

@@ -147,6 +147,46 @@ def test_cli_reader_formats(tmp_path, oracle_lib):
     oidx.free()
 
 
+def _read_fastq_gz(path):
+    recs = []
+    with gzip.open(path, "rt") as f:
+        lines = f.read().split("\n")
+    i = 0
+    while i + 3 < len(lines) + 1 and i < len(lines) and lines[i]:
+        recs.append((lines[i][1:], lines[i + 1], lines[i + 3]))
+        i += 4
+    return recs
+
+
+def test_cli_extract_writes_called_reads(tmp_path):
+    """--extract: records of reads called as the category go to <prefix>_<category><ext>.gz in classification order
+    (src/dehost_main.cpp:515-536, include/result.hpp:118-128); sequences come out as dna5 letters"""
+    fq = os.path.join(G, "cfg1_reads.fastq.gz")
+    originals = {r[0].split(" ")[0]: r for r in _read_fastq_gz(fq)}
+    pre = str(tmp_path / "out")
+    rc, out, err = run_cli(["--db", os.path.join(G, "cfg1.idx"), "--extract", "microbial", "-p", pre, "--num_reads_to_fit", "20", fq], str(tmp_path))
+    assert rc == 0, err
+    assert_same_tsv(out, open(os.path.join(G, "cfg1_expected_extract.tsv")).read())
+    want_ids = [x.split("\t")[1] for x in out.strip().split("\n") if x.split("\t")[2] == "microbial"]
+    got = _read_fastq_gz(pre + "_microbial.fastq.gz")
+    assert [g[0].split(" ")[0] for g in got] == want_ids and len(got) > 20
+    for gid, seq, qual in got:
+        o = originals[gid.split(" ")[0]]
+        assert gid == o[0] and qual == o[2]
+        assert seq == "".join(c if c in "ACGT" else "N" for c in o[1].upper())
+    assert not os.path.exists(pre + "_host.fastq.gz")
+    # all categories, default prefix "charon" in the working directory
+    rc, out, err = run_cli(["--db", os.path.join(G, "cfg1.idx"), "-e", "all", fq], str(tmp_path))
+    assert rc == 0, err
+    n_m = len(_read_fastq_gz(str(tmp_path / "charon_microbial.fastq.gz")))
+    n_h = len(_read_fastq_gz(str(tmp_path / "charon_host.fastq.gz")))
+    rows = out.strip().split("\n")
+    assert n_m == sum(1 for x in rows if x.split("\t")[2] == "microbial") and n_h == sum(1 for x in rows if x.split("\t")[2] == "host")
+    # an unknown category is logged, nothing runs, exit status 0
+    rc, out, err = run_cli(["--db", os.path.join(G, "cfg1.idx"), "-e", "fungi", fq], str(tmp_path))
+    assert rc == 0 and out == "" and "Cannot extract fungi" in open(tmp_path / "charon.log").read()
+
+
 def test_cli_self_check_catches_foreign_index(tmp_path, oracle_lib):
     """if the reference FASTA named in the index does not hash into its bin, the loader says so loudly (hard part H6)"""
     r = util.rng(44)
