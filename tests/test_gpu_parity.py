@@ -297,3 +297,54 @@ def test_row_sharded_mode_equals_replica_mode(api, oracle_lib):
         for sh in shards:
             sh.destroy()
         oidx.free()
+
+
+def test_randomised_parameter_sweep(api, oracle_lib):
+    """many small random configurations: k, w, bin count / category map (single- and multi-bin, W = 1..3), read lengths,
+    N density, low-complexity inserts, paired or single -- every integer column bit-exact against the oracle"""
+    r = util.rng(2024)
+    for trial in range(24):
+        k = int(r.integers(3, 28))
+        w = int(k + r.integers(0, 30))
+        B = int(r.choice([1, 2, 3, 5, 9, 33, 64, 65, 130]))
+        C = int(min(B, r.integers(2, 7))) if B > 1 else 1
+        b2c = [int(x) for x in r.integers(0, C, B)]
+        for c in range(C):  # every category owns at least one bin
+            b2c[c % B] = c
+        if B == 1:
+            continue  # call_host / call_category need >= 2 categories
+        cats = ["human"] + ["c%d" % i for i in range(1, C)]
+        gs = [util.random_seq(r, int(r.integers(300, 3000))) for _ in range(B)]
+        oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], b2c, cats, k=k, w=w, bin_size=int(r.integers(2000, 60000)),
+                                       fill_seed=trial, fill=float(r.choice([0.0, 0.05, 0.2])))
+        n = int(r.integers(1, 150))
+        paired = bool(r.integers(0, 2)) or C > 2  # single-end call_host uses categories 0/1 only; fine for C == 2
+        reads = util.sample_reads(r, gs, n, (0, int(r.integers(5, 1200))), sub_rate=0.03, random_fraction=0.2)
+        mates = util.sample_reads(r, gs, n, (0, int(r.integers(5, 400))), sub_rate=0.03) if paired else None
+
+        def spice(s):
+            a = bytearray(s)
+            if len(a) > 10 and r.random() < 0.3:
+                for p in r.integers(0, len(a), int(r.integers(1, 6))):
+                    a[int(p)] = ord("N")
+            if len(a) > 60 and r.random() < 0.2:
+                p = int(r.integers(0, len(a) - 50))
+                a[p:p + 50] = (b"AT" * 25) if r.random() < 0.5 else b"G" * 50
+            return bytes(a)
+        reads = [spice(s) for s in reads]
+        if mates:
+            mates = [spice(s) for s in mates]
+        check(api, oracle_lib, oidx, reads, mates)
+        oidx.free()
+
+
+def test_long_reads(api, oracle_lib):
+    """reads far longer than a wavefront's usual share (250 kb next to 100 b in the same batch)"""
+    r = util.rng(99)
+    gs = [util.random_seq(r, 300000), util.random_seq(r, 300000)]
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [0, 1], ["host", "microbial"])
+    reads = [util.mutate(r, gs[0][1000:251000], 0.05), gs[1][:100], util.mutate(r, gs[1][5:120005], 0.1), b"ACGT" * 20000] + \
+        util.sample_reads(r, gs, 70, (100, 3000))
+    gpu, orc = check(api, oracle_lib, oidx, reads)
+    assert gpu["num_hashes"][0] > 20000 and gpu["conf"][0] == 255
+    oidx.free()
