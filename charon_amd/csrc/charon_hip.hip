@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -113,6 +114,7 @@ struct K1Args {
     const uint64_t *wave_base;
     uint32_t *wave_count;    // MODE_ROWS: entries written by wavefront g
     const uint8_t *read_bin; // MODE_EMPLACE: target bin of "read" (genome chunk) r
+    uint32_t ablate;         // diagnostics only (CHN_ABLATE env): 1 = skip the gathers, 2 = skip hash+gathers
 };
 
 template <int W>
@@ -251,6 +253,7 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
 #pragma unroll
                 for (uint32_t i = 0; i < 5; ++i)
                     if (i < a.h) {
+                        if (a.ablate) { pend[i][0] = rows_[i]; for (int w = 1; w < W; ++w) pend[i][w] = val; continue; }
                         const uint64_t *p = a.words + (rows_[i] - a.row_begin) * W;
                         // non-temporal: a probed line is never reused, keep it from displacing the row/base lines in L2
                         if (W == 1) {
@@ -1299,6 +1302,7 @@ static int submit_impl(chn_stream *s, const chn_batch *b, bool list_mode) {
     for (uint32_t bb = 0; bb < 8 && bb < d.bins; ++bb) a.b2c_packed |= (uint64_t)d.bin_to_category[bb] << (8 * bb);
     a.bases = bases; a.nmask = nmask; a.off1 = off1; a.off2 = off2; a.len1 = sl.len1; a.len2 = sl.len2;
     a.order = s->d_order.as<uint32_t>();
+    if (const char *ab = std::getenv("CHN_ABLATE")) a.ablate = (uint32_t)std::atoi(ab);
     a.num_hashes = sl.d_num_hashes.as<uint32_t>(); a.counts = sl.d_counts.as<uint32_t>(); a.unique = sl.d_unique.as<uint32_t>();
     a.rows = list_mode ? s->d_list.as<uint64_t>() : s->d_rows.as<uint64_t>(); a.row_owner = s->d_rowown.as<uint8_t>();
     a.wave_base = s->d_wbase.as<uint64_t>(); a.wave_count = s->d_wcount.as<uint32_t>();
