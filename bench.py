@@ -36,6 +36,9 @@ WORKLOADS = {
                 desc="5 kb synthetic reads vs 39 GB stand-in index (B=100, TB=128, W=2, S=2437500000, h=3, k=19, w=41)"),
     "cfg2": dict(bins=2, rows=1 << 27, genome_len=1 << 24, reads=1 << 20, read_len=5000, fill=0.215,
                  desc="5 kb synthetic reads vs 2-category 1 GiB index (B=2, TB=64, W=1, S=2^27, h=3, k=19, w=41)"),
+    # BASELINE configs[4]: paired short reads (2 x 150 b) vs an 8-category index (one bin per category, one named "host")
+    "cfg5": dict(bins=8, rows=1 << 27, genome_len=1 << 23, reads=1 << 23, read_len=150, fill=0.215, paired=True,
+                 desc="paired 2 x 150 b synthetic reads vs 8-category 1 GiB index (B=8, TB=64, W=1, S=2^27, h=3, k=19, w=41)"),
     "small": dict(bins=2, rows=1 << 20, genome_len=1 << 16, reads=1 << 14, read_len=1000, fill=0.1,
                   desc="1 kb synthetic reads vs toy 2-category index (harness check)"),
 }
@@ -91,16 +94,22 @@ def main():
     if args.read_len:
         wl["read_len"] = args.read_len
     B, S, n_reads, L = wl["bins"], wl["rows"], wl["reads"], wl["read_len"]
-    b2c = [b % 2 for b in range(B)]  # even bins: category 0 (human), odd bins: category 1 (microbial)
-    categories = ["human", "microbial"]
+    paired = bool(wl.get("paired"))
+    if paired:
+        b2c = list(range(B))          # one category per bin, category 0 = host
+        categories = ["host"] + ["c%d" % i for i in range(1, B)]
+    else:
+        b2c = [b % 2 for b in range(B)]  # even bins: category 0 (human), odd bins: category 1 (microbial)
+        categories = ["human", "microbial"]
+    ncat = len(categories)
 
     t_setup = time.time()
     rows_mode = args.shard == "rows"
     if rows_mode:
         rlo, rhi = shard.shard_range(S, rank, world)
-        desc = api.make_desc(B, S, b2c, 2, 0, device=local, row_begin=rlo, row_end=rhi)
+        desc = api.make_desc(B, S, b2c, ncat, 0, device=local, row_begin=rlo, row_end=rhi)
     else:
-        desc = api.make_desc(B, S, b2c, 2, 0, device=local)
+        desc = api.make_desc(B, S, b2c, ncat, 0, device=local)
     index = api.Index(desc)
     index.synth_fill(43, wl["fill"])
     genomes = api.synth_genomes(local, 43, B, wl["genome_len"])
@@ -108,14 +117,26 @@ def main():
     # weak scaling: rank r classifies global reads [r*n, (r+1)*n) of one seeded read set (charon_amd/shard.py)
     lo, hi = (0, n_reads) if rows_mode else shard.shard_range(n_reads * world, rank, world)
     Lmax = max(L, args.read_len_max)
-    reads = api.synth_reads(local, 42, genomes, B, wl["genome_len"], hi - lo, L, Lmax, 0.05, 0.10, 40.0, first_read_id=lo)
+    nseg = 2 if paired else 1   # mates are consecutive synthetic reads 2i, 2i+1 of one read set
+    reads = api.synth_reads(local, 42, genomes, B, wl["genome_len"], (hi - lo) * nseg, L, Lmax, 0.05, 0.10, 40.0, first_read_id=lo * nseg)
+    seg = {}
+    if paired:
+        off = api.device_download(local, reads.seg1_offset, n_reads * 2 * 8, np.uint64)
+        ln = api.device_download(local, reads.seg1_length, n_reads * 2 * 4, np.uint32)
+        for name, arr in (("o1", off[0::2]), ("o2", off[1::2]), ("l1", ln[0::2]), ("l2", ln[1::2])):
+            seg[name] = api.device_malloc(local, arr.nbytes)
+            api.device_upload(local, seg[name], np.ascontiguousarray(arr))
     stream = api.Stream(index, n_reads, reads.n_bases, profile=True)
-    stream.set_model(api.default_model(2, 0))
+    stream.set_model(api.default_model(ncat, 0, paired=paired))
     setup_s = time.time() - t_setup
 
     def submit():
-        stream.submit_device(n_reads, reads.n_bases, reads.bases2, reads.seg1_offset, reads.seg1_length, reads.mean_quality,
-                             reads.compression)
+        if paired:
+            stream.submit_device(n_reads, reads.n_bases, reads.bases2, seg["o1"], seg["l1"], reads.mean_quality, reads.compression,
+                                 seg2_offset=seg["o2"], seg2_length=seg["l2"])
+        else:
+            stream.submit_device(n_reads, reads.n_bases, reads.bases2, reads.seg1_offset, reads.seg1_length, reads.mean_quality,
+                                 reads.compression)
 
     def run_steps_rows(k):
         """row-sharded chain: minimise (all ranks, same batch) -> probe own rows -> ONE sum all-reduce -> AND/count/call"""
@@ -173,7 +194,7 @@ def main():
 
     # summary counters (ResultSummary, include/result.hpp:18-25): the one collective of the read-sharded mode
     call = api.device_download(local, res.call, n_reads, np.uint8)
-    summary = shard.summary_counts(call, 2)
+    summary = shard.summary_counts(call, ncat)
     if world > 1 and not rows_mode:  # in rows mode every rank already holds the calls of the whole batch
         summary = shard.merge_summary(summary, dist, coll_dev)
 
@@ -221,7 +242,7 @@ def main():
                        "sharding": ("index rows sharded over ranks, same batch on every rank, one sum all-reduce of probe words per batch" if rows_mode else
                                     "reads sharded over ranks, full index replica per GPU, no data-path collective"),
                        "mean_minimisers_per_read": total_min / n_reads, "borderline_reads": int(flags.sum()),
-                       "summary_counts": {"human": int(summary[0]), "microbial": int(summary[1]), "unclassified": int(summary[2])},
+                       "summary_counts": dict([(categories[c], int(summary[c])) for c in range(ncat)] + [("unclassified", int(summary[ncat]))]),
                        "setup_seconds": round(setup_s, 1), "pcie_inclusive_reads_per_s": pcie_rate},
             "roofline": {"bound": "hbm", "kernel": "k_minimise_probe", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
@@ -229,7 +250,7 @@ def main():
                          "other_kernels_avg_ms": {"k_count_rows": k2_ms / max(k2_n, 1), "k_model_call": k3_ms / max(k3_n, 1),
                                                   "whole_chain": chain_ms / max(chain_n, 1)}},
         }
-        if world == 1 and not args.no_cpu_baseline and not rows_mode:
+        if world == 1 and not args.no_cpu_baseline and not rows_mode and not paired:
             out["cpu_baseline"] = cpu_baseline(api, index, reads, res, n_reads, args, local, categories, b2c)
     stream.destroy()
     index.destroy()

@@ -64,7 +64,7 @@ EXPORTS = ["chn_index_create", "chn_index_upload_rows", "chn_index_device_words"
            "chn_model_set", "chn_batch_submit", "chn_batch_wait", "chn_stream_sync", "chn_classify_counts", "chn_stream_profile",
            "chn_stream_last_batch_bytes", "chn_synth_genomes", "chn_synth_fill_index", "chn_synth_plant", "chn_synth_reads",
            "chn_device_free", "chn_device_download", "chn_device_malloc", "chn_device_upload", "chn_shard_minimise",
-           "chn_shard_probe", "chn_shard_finish", "chn_last_error", "chn_version"]
+           "chn_shard_probe", "chn_shard_finish", "chn_minimisers", "chn_index_emplace", "chn_last_error", "chn_version"]
 
 _L.chn_last_error.restype = C.c_char_p
 _L.chn_version.restype = C.c_char_p
@@ -95,6 +95,8 @@ _L.chn_device_upload.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
 _L.chn_shard_minimise.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(C.c_uint64)]
 _L.chn_shard_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
 _L.chn_shard_finish.argtypes = [C.c_void_p, C.c_void_p]
+_L.chn_minimisers.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+_L.chn_index_emplace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
 _L.chn_device_download.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
 
 
@@ -164,6 +166,10 @@ class Index:
         _chk(_L.chn_index_device_words(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def emplace(self, values, bin_index):
+        values = np.ascontiguousarray(values, dtype=np.uint64)
+        _chk(_L.chn_index_emplace(self.h, values.ctypes.data, values.size, bin_index))
+
     def synth_fill(self, seed, density):
         _chk(_L.chn_synth_fill_index(self.h, seed, density))
 
@@ -224,6 +230,15 @@ class Stream:
         b.mean_quality = ptr(mean_quality, np.float32)
         b.compression = ptr(compression, np.float32)
         return b, keep, n
+
+    def minimisers_host(self, packed):
+        """all minimisers of the batch (with repeats) as a uint64 array"""
+        b, keep, n = self._host_batch(packed, None, None)
+        cap = int(packed["n_bases"])
+        out = np.zeros(max(cap, 1), np.uint64)
+        e = C.c_uint64()
+        _chk(_L.chn_minimisers(self.h, C.byref(b), out.ctypes.data, cap, C.byref(e)))
+        return out[:e.value]
 
     # ---- row-sharded mode (see include/charon_hip.h) ----
     def shard_minimise_host(self, packed):

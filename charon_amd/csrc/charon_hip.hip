@@ -558,6 +558,22 @@ __global__ __launch_bounds__(256) void k_and_partial(const ShardArgs a) {
         }
     }
 }
+__global__ __launch_bounds__(256) void k_compact_list(const ShardArgs a, uint64_t *out) {
+    const uint32_t g = blockIdx.x, count = a.wave_count[g];
+    const uint64_t *list = a.list + a.wave_base[g];
+    uint64_t *dst = out + a.cbase[g];
+    for (uint32_t e = threadIdx.x; e < count; e += blockDim.x) dst[e] = list[e];
+}
+__global__ void k_emplace_values(uint64_t *words, const uint64_t *values, uint64_t n, uint32_t bin, uint64_t S, uint64_t row_begin, uint64_t row_end,
+                                 uint32_t shift, uint32_t h, uint32_t W) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t v = values[i];
+        for (uint32_t j = 0; j < h; ++j) {
+            const uint64_t row = hash_and_fit_row(v, c_ibf_seeds[j], S, shift);
+            if (row >= row_begin && row < row_end) atomicOr((unsigned long long *)&words[(row - row_begin) * W + (bin >> 6)], 1ULL << (bin & 63));
+        }
+    }
+}
 __global__ void k_counts_to_u64(const uint32_t *c, uint32_t n, uint64_t *out /* n + 1 */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = c[i];
@@ -1425,6 +1441,51 @@ extern "C" int chn_shard_minimise(chn_stream *s, const chn_batch *b, uint64_t *n
     s->shard_entries = total;
     s->shard_open = true;
     *n_entries = total;
+    return CHN_OK;
+}
+
+extern "C" int chn_minimisers(chn_stream *s, const chn_batch *b, uint64_t *host_values, uint64_t capacity, uint64_t *n_values) {
+    if (!s || !b || !n_values) return fail(CHN_E_INVALID, "chn_minimisers: null argument");
+    uint64_t total = 0;
+    int rc = chn_shard_minimise(s, b, &total);
+    if (rc) return rc;
+    s->shard_open = false;  // nothing else of the sharded chain follows
+    *n_values = total;
+    if (total == 0) return CHN_OK;
+    if (!host_values || capacity < total) return fail(CHN_E_CAPACITY, "chn_minimisers: output buffer too small (need " + std::to_string(total) + " values)");
+    // compact the per-wavefront logs into the (unused here) row buffer, then copy out
+    if ((rc = s->d_rows.ensure(total * 8))) return rc;
+    const Slot &sl = s->slot[s->head];
+    const uint32_t n_waves = (uint32_t)((sl.n_reads + WAVE - 1) / WAVE);
+    const ShardArgs sa = shard_args(s, s->idx, nullptr);
+    hipLaunchKernelGGL(k_compact_list, dim3(n_waves), dim3(256), 0, s->stream, sa, s->d_rows.as<uint64_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host_values, s->d_rows.p, total * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return CHN_OK;
+}
+
+extern "C" int chn_index_emplace(chn_index *idx, const uint64_t *host_values, uint64_t n_values, uint32_t bin) {
+    if (!idx || (!host_values && n_values)) return fail(CHN_E_INVALID, "chn_index_emplace: null argument");
+    if (bin >= idx->d.bins) return fail(CHN_E_INVALID, "chn_index_emplace: bin out of range");
+    if (n_values == 0) return CHN_OK;
+    const chn_index_desc &d = idx->d;
+    HIPCHK(hipSetDevice(d.device));
+    uint64_t *dv = nullptr;
+    const uint64_t chunk = 1ULL << 26;  // 512 MiB of values at a time
+    HIPCHK(hipMalloc((void **)&dv, std::min(chunk, n_values) * 8));
+    for (uint64_t o = 0; o < n_values; o += chunk) {
+        const uint64_t m = std::min(chunk, n_values - o);
+        hipError_t e = hipMemcpy(dv, host_values + o, m * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_emplace_values, dim3((uint32_t)std::min<uint64_t>(65535, (m + 255) / 256)), dim3(256), 0, 0, idx->words, dv, m, bin,
+                               d.bin_size, d.row_begin, d.row_end, (uint32_t)d.hash_shift, (uint32_t)d.hash_funs, (uint32_t)d.bin_words);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) { (void)hipFree(dv); return fail(CHN_E_HIP, std::string("chn_index_emplace: ") + hipGetErrorString(e)); }
+    }
+    HIPCHK(hipFree(dv));
     return CHN_OK;
 }
 

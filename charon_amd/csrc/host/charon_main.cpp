@@ -36,6 +36,8 @@
 #include <stdexcept>
 #include <string>
 #include <sys/stat.h>
+#include <unistd.h>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
@@ -1235,6 +1237,334 @@ int dehost_main(DehostArguments &opt) {
     return 0;
 }
 
+// ===================================================================================================
+// charon index  (src/index_main.cpp; include/index_arguments.hpp:9-27; include/store_index.hpp:12-17)
+// ===================================================================================================
+struct IndexArguments {
+    std::string input_file, prefix, tmp_dir, log_file = "charon.log";
+    uint8_t window_size = 41, kmer_size = 19;
+    uint64_t bits = 4294967293ULL;  // numeric_limits<uint32_t>::max() - 2
+    uint8_t num_hash = 3;
+    double max_fpr = 0.01;
+    uint8_t threads = 1, verbosity = 0;
+    bool optimize = false;
+    int device = 0;
+};
+
+bool parse_index(int argc, char **argv, IndexArguments &opt) {
+    std::vector<std::string> pos;
+    for (int i = 0; i < argc; ++i) {
+        std::string a = argv[i], val;
+        bool has_val = false;
+        if (a.size() > 2 && a[0] == '-' && a[1] == '-') {
+            const size_t eq = a.find('=');
+            if (eq != std::string::npos) { val = a.substr(eq + 1); a = a.substr(0, eq); has_val = true; }
+        }
+        auto need = [&]() -> std::string {
+            if (has_val) return val;
+            if (i + 1 >= argc) throw ParseError(a + ": 1 required");
+            return argv[++i];
+        };
+        if (a == "-h" || a == "--help") {
+            std::cout << "Build an index (IBF) for a number of references split into a small number of bins.\n"
+                         "Usage: charon index [OPTIONS] <input>\n\nPositionals:\n  <input> FILE REQUIRED   Tab separated file with columns for filename and category\n\n"
+                         "Options:\n  -w INT=41               Window size for (w,k,s)-minimers (must be <=k).\n  -k INT=19               K-mer size for (w,k,s)-minimers.\n"
+                         "  -t,--threads INT=1      Maximum number of threads to use.\n  -p,--prefix FILE        Prefix for the output index.\n"
+                         "  --temp DIR              Temporary directory for index construction files.\n  --log FILE              File for log\n"
+                         "  --optimize              Compress the number of bins for improved classification run time\n  -v                      Verbosity of logging.\n";
+            return false;
+        }
+        else if (a == "-w") opt.window_size = (uint8_t)parse_uint("w", need(), 255);
+        else if (a == "-k") opt.kmer_size = (uint8_t)parse_uint("k", need(), 255);
+        else if (a == "-t" || a == "--threads") opt.threads = (uint8_t)parse_uint("threads", need(), 255);
+        else if (a == "-p" || a == "--prefix") opt.prefix = need();
+        else if (a == "--temp") opt.tmp_dir = need();
+        else if (a == "--log") opt.log_file = need();
+        else if (a == "--optimize") opt.optimize = true;
+        else if (a.size() >= 2 && a[0] == '-' && a.find_first_not_of('v', 1) == std::string::npos) opt.verbosity = (uint8_t)std::min<size_t>(255, opt.verbosity + a.size() - 1);
+        else if (!a.empty() && a[0] == '-' && a.size() > 1) throw ParseError("The following argument was not expected: " + a);
+        else pos.push_back(a);
+    }
+    if (pos.empty()) throw ParseError("<input> is required");
+    if (pos.size() > 1) throw ParseError("The following argument was not expected: " + pos[1]);
+    if (!is_file(pos[0])) throw ParseError("<input>: File does not exist: " + pos[0]);
+    if (!opt.prefix.empty() && path_exists(opt.prefix)) throw ParseError("--prefix: Path already exists: " + opt.prefix);
+    opt.input_file = pos[0];
+    return true;
+}
+
+std::string make_absolute(const std::string &p) {
+    if (!p.empty() && p[0] == '/') return p;
+    char buf[4096];
+    if (!::getcwd(buf, sizeof buf)) return p;
+    return std::string(buf) + "/" + p;
+}
+
+// bin_size_in_bits (src/utils.cpp:75-90)
+uint64_t bin_size_in_bits(const IndexArguments &opt, uint64_t num_elements) {
+    const double numerator = -static_cast<double>(num_elements * opt.num_hash);
+    const double denominator = std::log(1 - std::exp(std::log(opt.max_fpr) / opt.num_hash));
+    const double result = std::ceil(numerator / denominator);
+    if (result > (double)opt.bits) { g_log.warn("Require more bits than available for max_fpr"); return opt.bits; }
+    return (uint64_t)result;
+}
+
+// sdsl::sd_vector construction from ascending set-bit positions delivered block-wise, and the cereal
+// binary archive of Index::serialize (include/index.hpp:122-131).  The two trailing select_support_mcl structures of
+// sd_vector are not written: this build's loader does not need them, the reference's loader does (documented gap).
+struct EliasFanoWriter {
+    uint64_t size = 0, ones = 0, high_bits = 0, k = 0;
+    uint8_t wl = 0;
+    std::vector<uint64_t> low, high;
+    static unsigned hi(uint64_t x) { return x ? 63u - (unsigned)__builtin_clzll(x) : 0u; }
+    void begin(uint64_t universe, uint64_t n_ones) {
+        size = universe; ones = n_ones; k = 0;
+        unsigned logm = hi(ones) + 1;
+        const unsigned logn = hi(size) + 1;
+        if (logm == logn) --logm;
+        wl = (uint8_t)(logn - logm);
+        high_bits = ones + (1ULL << logm);
+        low.assign((ones * wl + 63) / 64 + 1, 0);
+        high.assign((high_bits + 63) / 64, 0);
+    }
+    void add(uint64_t pos) {
+        if (wl) {
+            const uint64_t v = pos & ((1ULL << wl) - 1), bit = k * wl, wd = bit >> 6, sh = bit & 63;
+            low[wd] |= v << sh;
+            if (sh + wl > 64) low[wd + 1] |= v >> (64 - sh);
+        }
+        const uint64_t hp = (pos >> wl) + k;
+        high[hp >> 6] |= 1ULL << (hp & 63);
+        ++k;
+    }
+};
+
+struct BinWriter {
+    std::ofstream os;
+    explicit BinWriter(const std::string &path) : os(path, std::ios::binary) { if (!os) throw std::runtime_error("cannot create " + path); }
+    template <class T> void pod(const T &v) { os.write(reinterpret_cast<const char *>(&v), sizeof(T)); }
+    void str(const std::string &s) { pod<uint64_t>(s.size()); os.write(s.data(), (std::streamsize)s.size()); }
+    void int_vector(uint8_t width, uint64_t bit_size, const std::vector<uint64_t> &words) {
+        const uint64_t n_words = (bit_size + 63) >> 6;
+        pod<uint8_t>(width); pod<float>(1.5f); pod<uint64_t>(n_words); pod<uint64_t>(bit_size);
+        os.write(reinterpret_cast<const char *>(words.data()), (std::streamsize)(n_words * 8));
+    }
+};
+
+int index_main(IndexArguments &opt) {
+    g_log.open(opt.log_file, opt.verbosity);
+    // src/index_main.cpp:274-291
+    if (opt.window_size < opt.kmer_size) throw std::logic_error("W must be greater than K");
+    if (opt.kmer_size == 0) throw std::logic_error("K must be a positive integer");
+    if (opt.kmer_size > 27) throw std::logic_error("K must be at most 27 for the dna5 alphabet (5^k has to fit 64 bits)");
+    opt.input_file = make_absolute(opt.input_file);
+    if (!opt.prefix.empty()) opt.prefix += ".idx"; else opt.prefix = opt.input_file + ".idx";
+    g_log.info(std::string("Running charon index\n\nCharon version: ") + CHARON_VERSION);
+
+    // parse_input_file (:75-116).  Category order = iteration order of an unordered_set<string>, reproduced by using the same
+    // container of the same standard library (libstdc++) -- quirk A.9.
+    IndexMeta meta;
+    meta.window_size = opt.window_size; meta.kmer_size = opt.kmer_size; meta.max_fpr = opt.max_fpr;
+    {
+        std::ifstream in(opt.input_file);
+        if (!in) { g_log.error("Error opening file " + opt.input_file); return 1; }
+        std::unordered_set<std::string> categories;
+        std::string line;
+        uint8_t next_bin = 0;
+        while (std::getline(in, line)) {
+            if (line.empty()) continue;
+            const size_t tab = line.find('\t');
+            if (tab == std::string::npos) continue;
+            const std::string path = make_absolute(line.substr(0, tab));
+            std::string name = line.substr(tab + 1);
+            const size_t tab2 = name.find('\t');
+            if (tab2 != std::string::npos) name.resize(tab2);
+            meta.bin_to_category[next_bin] = name;
+            categories.insert(name);
+            meta.filepath_to_bin.emplace_back(path, next_bin);
+            if (next_bin == 255) { g_log.warn("User has reached the maximum number of files which is 255 - ignoring any additional lines!"); break; }
+            next_bin++;
+        }
+        meta.num_bins = next_bin;
+        meta.categories.insert(meta.categories.end(), categories.begin(), categories.end());
+    }
+    if (meta.num_bins == 0) throw std::runtime_error("no 'path<TAB>category' lines in " + opt.input_file);
+    g_log.info("Found " + std::to_string(meta.filepath_to_bin.size()) + " files corresponding to " + std::to_string(meta.categories.size()) + " categories");
+
+    // count_and_store_hashes (:118-160) with the minimisers computed on the GPU.  A throw-away 1-bin index object carries k, w.
+    chn_index_desc d0;
+    std::memset(&d0, 0, sizeof d0);
+    d0.struct_size = sizeof d0; d0.device = opt.device; d0.kmer_size = opt.kmer_size; d0.window_size = opt.window_size; d0.hash_funs = opt.num_hash;
+    d0.num_categories = 1; d0.host_index = 255; d0.minimiser_seed = 0x8F3F73B5CF1C9ADEULL;
+    d0.bins = 1; d0.technical_bins = 64; d0.bin_size = 64; d0.hash_shift = (uint64_t)__builtin_clzll(64ULL); d0.bin_words = 1;
+    chn_index *probe_index = nullptr;
+    CHN_CHECK(chn_index_create(&d0, &probe_index));
+    const uint64_t max_bases = 1ULL << 28;
+    const uint32_t chunk = 4096;
+    chn_stream_cfg cfg;
+    cfg.struct_size = sizeof cfg; cfg.flags = 0; cfg.max_reads = max_bases / chunk + 65536; cfg.max_bases = max_bases;
+    chn_stream *stream = nullptr;
+    CHN_CHECK(chn_stream_create(probe_index, &cfg, &stream));
+
+    std::vector<std::vector<uint64_t>> hashes(meta.num_bins);  // distinct minimisers per bin (the reference spills them to <tmp>/<bin>.min)
+    for (const auto &fb : meta.filepath_to_bin) {
+        const uint8_t bin = fb.second;
+        meta.records_per_bin[bin] += 0;
+        BlockReader in(fb.first);
+        meta.num_files += 1;
+        std::vector<uint64_t> &set = hashes[bin];
+        uint64_t record_count = 0;
+        std::unique_ptr<HostBatch> hb(new HostBatch());
+        std::vector<uint64_t> values;
+        while (in.next(hb->blk1, 1u << 20, 64u << 20)) {
+            size_t begin = 0;
+            const size_t nrec = hb->blk1.recs.size();
+            while (begin < nrec) {  // sub-batches that fit the stream
+                uint64_t bases = 0;
+                size_t endi = begin;
+                while (endi < nrec && endi - begin < 60000 && bases + HostBatch::pad64(hb->blk1.recs[endi].seq_len) <= max_bases) { bases += HostBatch::pad64(hb->blk1.recs[endi].seq_len); ++endi; }
+                if (endi == begin) throw std::runtime_error("a reference sequence of " + fb.first + " is longer than 2^28 bases; split it");
+                HostBatch sub;
+                sub.blk1.recs.assign(hb->blk1.recs.begin() + (long)begin, hb->blk1.recs.begin() + (long)endi);
+                record_count += endi - begin;
+                begin = endi;
+                sub.pack(false, opt.threads, true);
+                if (sub.keep.empty()) continue;
+                // cut every record into chunks of 4096 bases overlapping by w-1: a chunk is created only where a whole window starts,
+                // so the union of the chunks' minimisers is exactly the record's minimiser set
+                std::vector<uint64_t> coff; std::vector<uint32_t> clen;
+                for (size_t i = 0; i < sub.keep.size(); ++i) {
+                    const uint64_t L = sub.len1[i], o = sub.off1[i];
+                    const uint64_t nwin = L >= opt.window_size ? L - opt.window_size + 1 : 1;
+                    const uint64_t nch = (nwin + chunk - 1) / chunk;
+                    for (uint64_t c = 0; c < nch; ++c) {
+                        const uint64_t st = c * chunk;
+                        coff.push_back(o + st);
+                        clen.push_back((uint32_t)std::min<uint64_t>(L - st, (uint64_t)chunk + opt.window_size - 1));
+                    }
+                }
+                chn_batch bt;
+                std::memset(&bt, 0, sizeof bt);
+                bt.struct_size = sizeof bt; bt.n_reads = coff.size(); bt.n_bases = sub.n_bases; bt.bases2 = sub.bases.data();
+                bt.nmask = sub.any_n ? sub.nmask.data() : nullptr; bt.seg1_offset = coff.data(); bt.seg1_length = clen.data();
+                values.resize(sub.n_bases + (uint64_t)opt.window_size * coff.size());
+                uint64_t nv = 0;
+                CHN_CHECK(chn_minimisers(stream, &bt, values.data(), values.size(), &nv));
+                set.insert(set.end(), values.begin(), values.begin() + (long)nv);
+                if (set.size() > (1u << 26)) { std::sort(set.begin(), set.end()); set.erase(std::unique(set.begin(), set.end()), set.end()); }
+            }
+        }
+        std::sort(set.begin(), set.end());
+        set.erase(std::unique(set.begin(), set.end()), set.end());
+        meta.records_per_bin[bin] += record_count;
+        meta.hashes_per_bin[bin] += set.size();
+        g_log.info("Added file " + fb.first + " with " + std::to_string(record_count) + " records and " + std::to_string(set.size()) + " hashes to bin " + std::to_string(bin));
+    }
+    chn_stream_destroy(stream);
+    chn_index_destroy(probe_index);
+
+    // optimize_layout (:162-236)
+    std::map<uint8_t, std::vector<uint8_t>> bucket_to_bins;
+    if (!opt.optimize) {
+        for (unsigned b = 0; b < meta.num_bins; ++b) bucket_to_bins[(uint8_t)b].push_back((uint8_t)b);
+    } else {
+        g_log.info("Optimize index bin layout");
+        std::vector<std::pair<uint8_t, uint64_t>> sorted(meta.hashes_per_bin.begin(), meta.hashes_per_bin.end());
+        std::stable_sort(sorted.begin(), sorted.end(), [](const std::pair<uint8_t, uint64_t> &l, const std::pair<uint8_t, uint64_t> &r) { return l.second < r.second; });
+        const uint64_t max_num_hashes = sorted.back().second / 2;
+        uint8_t next_bin = 0;
+        std::map<std::string, uint8_t> last_bin;
+        std::map<uint8_t, uint8_t> bin_to_bucket;
+        std::map<uint8_t, uint64_t> new_hashes, new_records;
+        for (const auto &pr : sorted) {
+            const uint8_t bin = pr.first;
+            const std::string &category = meta.bin_to_category.at(bin);
+            uint8_t assigned = next_bin;
+            auto it = last_bin.find(category);
+            if (it != last_bin.end()) {
+                if (new_hashes[it->second] + pr.second < max_num_hashes) assigned = it->second; else next_bin++;
+            } else {
+                next_bin++;
+            }
+            last_bin[category] = assigned;
+            bin_to_bucket[bin] = assigned;
+            bucket_to_bins[assigned].push_back(bin);
+            new_hashes[assigned] += pr.second;
+            new_records[assigned] += meta.records_per_bin.at(bin);
+        }
+        meta.hashes_per_bin = new_hashes; meta.records_per_bin = new_records;
+        std::map<uint8_t, std::string> b2c;
+        for (auto &fb : meta.filepath_to_bin) { const uint8_t bucket = bin_to_bucket[fb.second]; b2c[bucket] = meta.bin_to_category.at(fb.second); fb.second = bucket; }
+        meta.bin_to_category = b2c;
+        meta.num_bins = next_bin;
+    }
+
+    // build_index (:238-263)
+    uint64_t max_hashes = 0;
+    for (const auto &kv : meta.hashes_per_bin) max_hashes = std::max(max_hashes, kv.second);
+    const uint64_t S = std::max<uint64_t>(1, bin_size_in_bits(opt, max_hashes));
+    g_log.info("Create new IBF with " + std::to_string(meta.num_bins) + " bins and " + std::to_string(S) + " bits");
+    meta.bins = meta.num_bins; meta.bin_words = (meta.bins + 63) / 64; meta.technical_bins = meta.bin_words * 64;
+    meta.bin_size = S; meta.hash_shift = (uint64_t)__builtin_clzll(S); meta.hash_funs = opt.num_hash;
+    chn_index_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.struct_size = sizeof d; d.device = opt.device; d.kmer_size = opt.kmer_size; d.window_size = opt.window_size; d.hash_funs = opt.num_hash;
+    d.num_categories = (uint8_t)meta.categories.size(); d.host_index = meta.host_category_index(); d.minimiser_seed = 0x8F3F73B5CF1C9ADEULL;
+    d.bins = meta.bins; d.technical_bins = meta.technical_bins; d.bin_size = S; d.hash_shift = meta.hash_shift; d.bin_words = meta.bin_words;
+    for (uint64_t b = 0; b < meta.bins; ++b) d.bin_to_category[b] = meta.category_index(meta.bin_to_category.at((uint8_t)b));
+    chn_index *index = nullptr;
+    CHN_CHECK(chn_index_create(&d, &index));
+    for (const auto &kv : bucket_to_bins)
+        for (uint8_t bin : kv.second) {
+            CHN_CHECK(chn_index_emplace(index, hashes[bin].data(), hashes[bin].size(), kv.first));
+            std::vector<uint64_t>().swap(hashes[bin]);
+        }
+
+    // Index(...) compresses the IBF (include/index.hpp:43-50) and store_index writes it (include/store_index.hpp:12-17)
+    const uint64_t W = meta.bin_words, block_rows = std::max<uint64_t>(1, (256ULL << 20) / (8 * W));
+    std::vector<uint64_t> block(block_rows * W);
+    uint64_t ones = 0;
+    for (uint64_t r0 = 0; r0 < S; r0 += block_rows) {
+        const uint64_t nr = std::min(block_rows, S - r0);
+        CHN_CHECK(chn_index_download_rows(index, r0, nr, block.data()));
+        for (uint64_t i = 0; i < nr * W; ++i) ones += (uint64_t)__builtin_popcountll(block[i]);
+    }
+    EliasFanoWriter ef;
+    ef.begin(meta.technical_bins * S, ones);
+    for (uint64_t r0 = 0; r0 < S; r0 += block_rows) {
+        const uint64_t nr = std::min(block_rows, S - r0);
+        CHN_CHECK(chn_index_download_rows(index, r0, nr, block.data()));
+        for (uint64_t i = 0; i < nr * W; ++i) {
+            uint64_t x = block[i];
+            const uint64_t base = (r0 * W + i) * 64;
+            while (x) { ef.add(base + (uint64_t)__builtin_ctzll(x)); x &= x - 1; }
+        }
+    }
+    chn_index_destroy(index);
+    g_log.info("Saving index to file " + opt.prefix);
+    BinWriter w(opt.prefix);
+    w.pod<uint8_t>(meta.window_size); w.pod<uint8_t>(meta.kmer_size); w.pod<double>(meta.max_fpr);
+    w.pod<uint8_t>(meta.num_bins);
+    w.pod<uint64_t>(meta.categories.size());
+    for (const auto &c : meta.categories) w.str(c);
+    w.pod<uint64_t>(meta.filepath_to_bin.size());
+    for (const auto &fb : meta.filepath_to_bin) { w.str(fb.first); w.pod<uint8_t>(fb.second); }
+    w.pod<uint64_t>(meta.bin_to_category.size());
+    for (const auto &kv : meta.bin_to_category) { w.pod<uint8_t>(kv.first); w.str(kv.second); }
+    w.pod<uint32_t>(meta.num_files);
+    w.pod<uint64_t>(meta.records_per_bin.size());
+    for (const auto &kv : meta.records_per_bin) { w.pod<uint8_t>(kv.first); w.pod<uint64_t>(kv.second); }
+    w.pod<uint64_t>(meta.hashes_per_bin.size());
+    for (const auto &kv : meta.hashes_per_bin) { w.pod<uint8_t>(kv.first); w.pod<uint64_t>(kv.second); }
+    w.pod<uint64_t>(meta.bins); w.pod<uint64_t>(meta.technical_bins); w.pod<uint64_t>(meta.bin_size);
+    w.pod<uint64_t>(meta.hash_shift); w.pod<uint64_t>(meta.bin_words); w.pod<uint64_t>(meta.hash_funs);
+    w.pod<uint64_t>(ef.size); w.pod<uint8_t>(ef.wl);
+    w.int_vector(ef.wl ? ef.wl : 1, ef.ones * ef.wl, ef.low);
+    w.int_vector(1, ef.high_bits, ef.high);
+    if (!w.os) throw std::runtime_error("writing " + opt.prefix + " failed");
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -1243,9 +1573,28 @@ int main(int argc, char **argv) {
     if (sub == "-V" || sub == "--version") { std::cout << CHARON_VERSION << std::endl; return 0; }
     if (sub == "-h" || sub == "--help") {
         std::cout << "Charon: Dehost metagenomic reads\nUsage: charon [OPTIONS] SUBCOMMAND\n\nOptions:\n  -h,--help   Print this help message and exit\n  -V,--version   Show version\n\n"
-                     "Subcommands:\n  dehost   Dehost read file into host and other using index.\n"
-                     "  (index and classify are not part of the MI355X hot-path build)\n";
+                     "Subcommands:\n  index    Build an index (IBF) for a number of references split into a small number of bins.\n"
+                     "  dehost   Dehost read file into host and other using index.\n"
+                     "  (classify is not part of the MI355X hot-path build)\n";
         return 0;
+    }
+    if (sub == "index") {
+        IndexArguments iopt;
+        try {
+            if (const char *e = std::getenv("CHARON_DEVICE")) iopt.device = std::atoi(e);
+            if (!parse_index(argc - 2, argv + 2, iopt)) return 0;
+        } catch (ParseError &e) {
+            std::cerr << e.what() << "\nRun with --help for more information.\n";
+            return 105;
+        }
+        try {
+            index_main(iopt);
+            return 0;
+        } catch (std::exception &e) {
+            g_log.error(e.what());
+            std::cerr << "charon: " << e.what() << std::endl;
+            return 1;
+        }
     }
     if (sub != "dehost") { std::cerr << "The following argument was not expected: " << sub << "\nRun with --help for more information.\n"; return 109; }
     DehostArguments opt;

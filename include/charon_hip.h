@@ -192,6 +192,16 @@ int chn_shard_minimise(chn_stream *s, const chn_batch *b, uint64_t *n_entries);
 int chn_shard_probe(chn_stream *s, const chn_index *shard, uint64_t *dev_partial, uint64_t capacity_words);
 int chn_shard_finish(chn_stream *s, const uint64_t *dev_partial);
 
+/* ---- index construction (`charon index`, src/index_main.cpp:118-160,238-263) ------------------------------
+ * chn_minimisers: all minimisers emitted for the segments of `b` (seqan3 minimiser_hash with the stream's k, w), with
+ * repeats, in an unspecified but deterministic order, copied to host memory.  Replaces the per-record
+ * `record.sequence() | hash_adaptor` of count_and_store_hashes (:142-148); segments may overlap in `bases2`, which is how
+ * long reference sequences are cut into chunks overlapping by w-1 bases (the union over such chunks is exactly the set
+ * of window minima of the whole sequence).
+ * chn_index_emplace: ibf.emplace(value, bin) for every value (:252-255); values are host memory. */
+int chn_minimisers(chn_stream *s, const chn_batch *b, uint64_t *host_values, uint64_t capacity, uint64_t *n_values);
+int chn_index_emplace(chn_index *idx, const uint64_t *host_values, uint64_t n_values, uint32_t bin);
+
 /* Per-kernel device time accumulated since the last reset (CHN_STREAM_PROFILE streams only).
  * which: 0 = minimise+probe kernel, 1 = count kernel, 2 = model+call kernel, 3 = whole batch chain. */
 int chn_stream_profile(chn_stream *s, int which, double *total_ms, uint64_t *launches, int reset);

@@ -205,6 +205,55 @@ def test_cli_self_check_catches_foreign_index(tmp_path, oracle_lib):
     assert "self-check FAILED" in open(tmp_path / "charon.log").read()
 
 
+def test_cli_index_builds_the_same_index_as_the_oracle(tmp_path, oracle_lib):
+    """`charon index` (GPU minimisers of chunked references + device emplace + EF writer) must produce the same IBF words
+    and metadata as the oracle's sequential builder, and the file must load everywhere"""
+    r = util.rng(55)
+    files = []
+    for i, (nrec, L) in enumerate(((1, 30000), (3, 9000), (2, 50), (1, 5000), (2, 60))):
+        path = tmp_path / ("ref%d.fa" % i)
+        with open(path, "w") as f:
+            for j in range(nrec):
+                s = util.random_seq(r, L).decode()
+                if i == 1 and j == 1:
+                    s = s[:4000] + "N" * 30 + s[4030:6000].lower() + "AC" * 200 + s[6400:]
+                f.write(">rec%d_%d\n" % (i, j))
+                f.write("\n".join(s[k:k + 70] for k in range(0, len(s), 70)) + "\n")
+        files.append(str(path))
+    cats = ["microbial", "human", "microbial", "human", "microbial"]
+    tab = tmp_path / "in.tab"
+    with open(tab, "w") as f:
+        for p, c in zip(files, cats):
+            f.write("%s\t%s\n" % (p, c))
+    p = subprocess.run([EXE, "index", "-p", str(tmp_path / "built"), "--log", str(tmp_path / "i.log"), str(tab)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    got = oracle_lib.Index.load(str(tmp_path / "built.idx"))
+    want = oracle_lib.Index.from_fasta(list(zip(files, cats)), got.categories)
+    assert sorted(got.categories) == ["human", "microbial"]
+    assert (got.k, got.w, got.bins, got.bin_size, got.hash_funs) == (want.k, want.w, want.bins, want.bin_size, want.hash_funs)
+    assert list(got.bin_to_cat) == list(want.bin_to_cat)
+    assert np.array_equal(got.words(), want.words())
+    # and it is usable: dehost some reads with it, same TSV as the oracle on the oracle-built twin
+    reads = util.sample_reads(r, [open(f).read().split("\n", 1)[1].replace("\n", "").replace(">", "").encode()[:20000] for f in files[:2]], 60, (200, 900))
+    with open(tmp_path / "q.fastq", "w") as f:
+        for i, s in enumerate(reads):
+            s = s.decode().upper()
+            s = "".join(c if c in "ACGTN" else "A" for c in s)
+            f.write("@q%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)))
+    rc, out, err = run_cli(["--db", str(tmp_path / "built.idx"), str(tmp_path / "q.fastq")], str(tmp_path))
+    assert rc == 0, err
+    assert_same_tsv(out, want.dehost_files(str(tmp_path / "q.fastq")))
+    # --optimize merges small bins of one category; every reference must still hit its (new) bin completely (self-check v)
+    p = subprocess.run([EXE, "index", "--optimize", "-p", str(tmp_path / "opt"), "--log", str(tmp_path / "i.log"), str(tab)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    opt = oracle_lib.Index.load(str(tmp_path / "opt.idx"))
+    assert opt.bins == 4 and opt.ncat == 2  # the two tiny microbial files share a bucket (src/index_main.cpp:193-201)
+    rc, out, err = run_cli(["--db", str(tmp_path / "opt.idx"), str(tmp_path / "q.fastq")], str(tmp_path))
+    assert rc == 0 and "self-check FAILED" not in err
+    assert "reference file(s) all found" in open(tmp_path / "charon.log").read()
+    got.free(); want.free(); opt.free()
+
+
 def test_cli_errors(tmp_path):
     fq = os.path.join(G, "cfg1_reads.fastq.gz")
     rc, out, err = run_cli(["--db", os.path.join(G, "cfg1.idx"), "--threads", "256", fq], str(tmp_path))
