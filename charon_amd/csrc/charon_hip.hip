@@ -1269,14 +1269,19 @@ static int submit_impl(chn_stream *s, const chn_batch *b, bool list_mode) {
     const uint64_t *off1, *off2;
     if (!b->on_device) {
         // host-side validation of operand shapes before anything is launched
+        uint64_t total_len = 0;
         for (uint64_t i = 0; i < n; ++i) {
             const uint64_t o1 = b->seg1_offset[i], l1 = b->seg1_length[i];
+            total_len += l1 + (paired ? b->seg2_length[i] : 0);
             if ((o1 & 63) || o1 + l1 > b->n_bases) return fail(CHN_E_INVALID, "segment 1 of read " + std::to_string(i) + " is misaligned or out of range");
             if (paired) {
                 const uint64_t o2 = b->seg2_offset[i], l2 = b->seg2_length[i];
                 if ((o2 & 63) || o2 + l2 > b->n_bases) return fail(CHN_E_INVALID, "segment 2 of read " + std::to_string(i) + " is misaligned or out of range");
             }
         }
+        // the row / minimiser logs hold at most one entry per base of a segment; segments may overlap in `bases2`
+        // (chunked references), so it is the SUM of the segment lengths that must fit, not n_bases
+        if (total_len > s->cfg.max_bases) return fail(CHN_E_CAPACITY, "sum of segment lengths exceeds the stream's max_bases");
         int rc;
         if ((rc = upload(s->d_bases, b->bases2, b->n_bases / 4, s->stream))) return rc;
         if (b->nmask && (rc = upload(s->d_nmask, b->nmask, b->n_bases / 8, s->stream))) return rc;

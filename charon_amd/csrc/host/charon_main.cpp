@@ -1417,16 +1417,32 @@ int index_main(IndexArguments &opt) {
         std::unique_ptr<HostBatch> hb(new HostBatch());
         std::vector<uint64_t> values;
         while (in.next(hb->blk1, 1u << 20, 64u << 20)) {
+            record_count += hb->blk1.recs.size();
+            // a chromosome-sized record is handled as pieces of 2^26 bases overlapping by w-1 (same union-of-windows argument
+            // as for the 4096-base chunks below), so any record length fits the stream
+            std::vector<RecView> pieces;
+            uint32_t piece = 1u << 26;
+            if (const char *e = std::getenv("CHARON_INDEX_PIECE")) piece = std::max<uint32_t>(4096, (uint32_t)std::strtoul(e, nullptr, 10));  // test hook
+            for (const RecView &rv : hb->blk1.recs) {
+                if (rv.seq_len <= piece + opt.window_size) { pieces.push_back(rv); continue; }
+                for (uint64_t st = 0; st + opt.window_size <= rv.seq_len; st += piece) {
+                    RecView pv = rv;
+                    pv.seq = rv.seq + st;
+                    pv.seq_len = (uint32_t)std::min<uint64_t>(rv.seq_len - st, (uint64_t)piece + opt.window_size - 1);
+                    pv.qual = nullptr; pv.qual_len = 0;
+                    pieces.push_back(pv);
+                }
+            }
             size_t begin = 0;
-            const size_t nrec = hb->blk1.recs.size();
+            const size_t nrec = pieces.size();
             while (begin < nrec) {  // sub-batches that fit the stream
                 uint64_t bases = 0;
                 size_t endi = begin;
-                while (endi < nrec && endi - begin < 60000 && bases + HostBatch::pad64(hb->blk1.recs[endi].seq_len) <= max_bases) { bases += HostBatch::pad64(hb->blk1.recs[endi].seq_len); ++endi; }
-                if (endi == begin) throw std::runtime_error("a reference sequence of " + fb.first + " is longer than 2^28 bases; split it");
+                // chunks overlap by w-1 bases and every record adds one partial chunk: keep 1/8 of the capacity in reserve
+                while (endi < nrec && endi - begin < 60000 && bases + HostBatch::pad64(pieces[endi].seq_len) <= max_bases - max_bases / 8) { bases += HostBatch::pad64(pieces[endi].seq_len); ++endi; }
+                if (endi == begin) throw std::runtime_error("internal error: a piece of " + fb.first + " does not fit the stream");
                 HostBatch sub;
-                sub.blk1.recs.assign(hb->blk1.recs.begin() + (long)begin, hb->blk1.recs.begin() + (long)endi);
-                record_count += endi - begin;
+                sub.blk1.recs.assign(pieces.begin() + (long)begin, pieces.begin() + (long)endi);
                 begin = endi;
                 sub.pack(false, opt.threads, true);
                 if (sub.keep.empty()) continue;

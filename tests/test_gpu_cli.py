@@ -233,6 +233,11 @@ def test_cli_index_builds_the_same_index_as_the_oracle(tmp_path, oracle_lib):
     assert (got.k, got.w, got.bins, got.bin_size, got.hash_funs) == (want.k, want.w, want.bins, want.bin_size, want.hash_funs)
     assert list(got.bin_to_cat) == list(want.bin_to_cat)
     assert np.array_equal(got.words(), want.words())
+    # chromosome-sized records are processed in overlapping pieces; force tiny pieces to exercise that path
+    p2 = subprocess.run([EXE, "index", "-p", str(tmp_path / "pieces"), "--log", str(tmp_path / "i.log"), str(tab)], stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, env=dict(os.environ, CHARON_INDEX_PIECE="8192"))
+    assert p2.returncode == 0, p2.stderr.decode()
+    assert open(tmp_path / "pieces.idx", "rb").read() == open(tmp_path / "built.idx", "rb").read()
     # and it is usable: dehost some reads with it, same TSV as the oracle on the oracle-built twin
     reads = util.sample_reads(r, [open(f).read().split("\n", 1)[1].replace("\n", "").replace(">", "").encode()[:20000] for f in files[:2]], 60, (200, 900))
     with open(tmp_path / "q.fastq", "w") as f:
