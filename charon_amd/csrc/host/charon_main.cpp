@@ -1594,6 +1594,22 @@ int main(int argc, char **argv) {
                      "  (classify is not part of the MI355X hot-path build)\n";
         return 0;
     }
+    if (sub == "_records") {  // hidden diagnostic: dump what the block reader sees (no GPU involved)
+        try {
+            if (argc < 3) return 2;
+            BlockReader in(argv[2]);
+            RawBlock blk;
+            const size_t max_recs = argc > 3 ? (size_t)std::atol(argv[3]) : 1000, max_bytes = argc > 4 ? (size_t)std::atol(argv[4]) : (1u << 20);
+            while (in.next(blk, max_recs, max_bytes))
+                for (const RecView &r : blk.recs) {
+                    unsigned long long h = 1469598103934665603ULL; long qs = 0;
+                    for (uint32_t i = 0; i < r.seq_len; ++i) { h ^= (unsigned char)"ACGTN"[g_codes.t[(unsigned char)r.seq[i]] & 7]; h *= 1099511628211ULL; }
+                    for (uint32_t i = 0; i < r.qual_len; ++i) qs += r.qual[i] - 33;
+                    std::cout << std::string(r.id, r.id_len) << "\t" << r.seq_len << "\t" << r.qual_len << "\t" << qs << "\t" << h << "\n";
+                }
+            return 0;
+        } catch (std::exception &e) { std::cerr << "charon: " << e.what() << std::endl; return 1; }
+    }
     if (sub == "index") {
         IndexArguments iopt;
         try {
