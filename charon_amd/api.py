@@ -63,7 +63,7 @@ EXPORTS = ["chn_index_create", "chn_index_upload_rows", "chn_index_device_words"
            "chn_index_get_desc", "chn_index_destroy", "chn_model_default", "chn_stream_create", "chn_stream_destroy",
            "chn_model_set", "chn_batch_submit", "chn_batch_wait", "chn_stream_sync", "chn_classify_counts", "chn_stream_profile",
            "chn_stream_last_batch_bytes", "chn_synth_genomes", "chn_synth_fill_index", "chn_synth_plant", "chn_synth_reads",
-           "chn_device_free", "chn_device_download", "chn_device_malloc", "chn_device_upload", "chn_shard_minimise",
+           "chn_device_free", "chn_device_download", "chn_device_malloc", "chn_device_upload", "chn_host_alloc", "chn_host_free", "chn_shard_minimise",
            "chn_shard_probe", "chn_shard_finish", "chn_minimisers", "chn_index_emplace", "chn_last_error", "chn_version"]
 
 _L.chn_last_error.restype = C.c_char_p
@@ -91,6 +91,8 @@ _L.chn_synth_reads.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_uint64, C.c_
                                C.c_double, C.c_double, C.c_float, C.POINTER(SynthReadsOut)]
 _L.chn_device_free.argtypes = [C.c_int, C.c_void_p]
 _L.chn_device_malloc.argtypes = [C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]
+_L.chn_host_alloc.argtypes = [C.c_uint64, C.POINTER(C.c_void_p)]
+_L.chn_host_free.argtypes = [C.c_void_p]
 _L.chn_device_upload.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
 _L.chn_shard_minimise.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(C.c_uint64)]
 _L.chn_shard_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
@@ -332,6 +334,28 @@ def synth_reads(device, seed, dev_genomes, n_genomes, genome_len, n_reads, len_m
     _chk(_L.chn_synth_reads(device, seed, dev_genomes, n_genomes, genome_len, first_read_id, n_reads, len_min, len_max, sub_rate,
                             random_fraction, mean_quality, C.byref(out)))
     return out
+
+
+def pinned_array(shape, dtype):
+    """numpy array backed by page-locked host memory (chn_host_alloc); keep the returned array alive while in use.
+    The memory is released with host_free(arr)."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape))
+    p = C.c_void_p()
+    _chk(_L.chn_host_alloc(max(n * dtype.itemsize, 16), C.byref(p)))
+    buf = (C.c_char * (n * dtype.itemsize)).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+    _PINNED[arr.ctypes.data] = p.value
+    return arr
+
+
+_PINNED = {}
+
+
+def host_free(arr):
+    p = _PINNED.pop(arr.ctypes.data, None)
+    if p:
+        _chk(_L.chn_host_free(p))
 
 
 def device_malloc(device, nbytes):

@@ -909,6 +909,8 @@ struct HostModel {  // deep copy of chn_model
 struct Slot {
     DevBuf d_num_hashes, d_counts, d_unique, d_prob, d_call, d_conf, d_flags, d_acc;
     DevBuf d_len1, d_len2, d_mq, d_comp;  // staging of the small per-read arrays of host batches (read by k_model_call)
+    DevBuf d_bases, d_nmask, d_off1, d_off2;  // staging of the large arrays: per slot, so batch i+1 uploads while batch i computes
+    hipEvent_t uploaded = nullptr;
     const uint32_t *len1 = nullptr, *len2 = nullptr;
     const float *mq = nullptr, *comp = nullptr;
     uint64_t n_reads = 0;
@@ -925,8 +927,7 @@ struct chn_stream {
     chn_stream_cfg cfg;
     hipStream_t stream = nullptr;   // uploads, ordering, minimise+probe, count
     hipStream_t stream2 = nullptr;  // model+call
-    // staging of host batches (large arrays; reused by the next batch in stream order)
-    DevBuf d_bases, d_nmask, d_off1, d_off2;
+    hipStream_t stream0 = nullptr;  // host -> device uploads of host batches (truly asynchronous when the caller's memory is pinned)
     DevBuf d_order, d_hist, d_rows, d_rowown, d_wbase, d_wcount, d_model;
     DevBuf d_memo;                    // k_model_call memo table (cleared whenever the model changes)
     DevBuf d_list, d_cbase;           // row-sharded mode: minimiser value log, compact entry offsets
@@ -1104,6 +1105,7 @@ extern "C" int chn_stream_create(chn_index *idx, const chn_stream_cfg *cfg, chn_
     s->idx = idx; s->cfg = *cfg;
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream0, hipStreamNonBlocking);
     if (e != hipSuccess) { chn_stream_destroy(s); return fail(CHN_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
     const uint64_t n = cfg->max_reads, C = idx->d.num_categories;
     int rc = CHN_OK;
@@ -1111,6 +1113,7 @@ extern "C" int chn_stream_create(chn_index *idx, const chn_stream_cfg *cfg, chn_
         for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&sl.ev[i]);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.k2_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming);
         if (e != hipSuccess) { chn_stream_destroy(s); return fail(CHN_E_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
         if ((rc = sl.d_num_hashes.ensure(n * 4)) || (rc = sl.d_counts.ensure(n * C * 4)) || (rc = sl.d_unique.ensure(n * C * 4)) ||
             (rc = sl.d_prob.ensure(n * C * 8)) || (rc = sl.d_call.ensure(n)) || (rc = sl.d_conf.ensure(n)) || (rc = sl.d_flags.ensure(n)) ||
@@ -1136,16 +1139,18 @@ extern "C" int chn_stream_destroy(chn_stream *s) {
     (void)hipSetDevice(s->idx->d.device);
     if (s->stream) { (void)hipStreamSynchronize(s->stream); }
     if (s->stream2) { (void)hipStreamSynchronize(s->stream2); (void)hipStreamDestroy(s->stream2); }
+    if (s->stream0) { (void)hipStreamSynchronize(s->stream0); (void)hipStreamDestroy(s->stream0); }
     if (s->stream) (void)hipStreamDestroy(s->stream);
     for (Slot &sl : s->slot) {
         for (int i = 0; i < 8; ++i) if (sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
         if (sl.k2_done) (void)hipEventDestroy(sl.k2_done);
         if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
         DevBuf *bufs[] = {&sl.d_num_hashes, &sl.d_counts, &sl.d_unique, &sl.d_prob, &sl.d_call, &sl.d_conf, &sl.d_flags, &sl.d_acc,
-                          &sl.d_len1, &sl.d_len2, &sl.d_mq, &sl.d_comp};
+                          &sl.d_len1, &sl.d_len2, &sl.d_mq, &sl.d_comp, &sl.d_bases, &sl.d_nmask, &sl.d_off1, &sl.d_off2};
         for (DevBuf *b : bufs) b->release();
     }
-    DevBuf *bufs[] = {&s->d_bases, &s->d_nmask, &s->d_off1, &s->d_off2, &s->d_order, &s->d_hist, &s->d_rows, &s->d_rowown, &s->d_wbase, &s->d_wcount, &s->d_model, &s->d_list, &s->d_cbase, &s->d_memo};
+    DevBuf *bufs[] = {&s->d_order, &s->d_hist, &s->d_rows, &s->d_rowown, &s->d_wbase, &s->d_wcount, &s->d_model, &s->d_list, &s->d_cbase, &s->d_memo};
     for (DevBuf *b : bufs) b->release();
     delete s;
     return CHN_OK;
@@ -1283,16 +1288,21 @@ static int submit_impl(chn_stream *s, const chn_batch *b, bool list_mode) {
         // (chunked references), so it is the SUM of the segment lengths that must fit, not n_bases
         if (total_len > s->cfg.max_bases) return fail(CHN_E_CAPACITY, "sum of segment lengths exceeds the stream's max_bases");
         int rc;
-        if ((rc = upload(s->d_bases, b->bases2, b->n_bases / 4, s->stream))) return rc;
-        if (b->nmask && (rc = upload(s->d_nmask, b->nmask, b->n_bases / 8, s->stream))) return rc;
-        if ((rc = upload(s->d_off1, b->seg1_offset, n * 8, s->stream)) || (rc = upload(sl.d_len1, b->seg1_length, n * 4, s->stream))) return rc;
-        if (paired && ((rc = upload(s->d_off2, b->seg2_offset, n * 8, s->stream)) || (rc = upload(sl.d_len2, b->seg2_length, n * 4, s->stream)))) return rc;
-        if (b->mean_quality && (rc = upload(sl.d_mq, b->mean_quality, n * 4, s->stream))) return rc;
-        if (b->compression && (rc = upload(sl.d_comp, b->compression, n * 4, s->stream))) return rc;
-        bases = s->d_bases.as<uint32_t>();
-        nmask = b->nmask ? s->d_nmask.as<uint32_t>() : nullptr;
-        off1 = s->d_off1.as<uint64_t>(); sl.len1 = sl.d_len1.as<uint32_t>();
-        off2 = paired ? s->d_off2.as<uint64_t>() : nullptr; sl.len2 = paired ? sl.d_len2.as<uint32_t>() : nullptr;
+        // uploads go through the copy stream; the compute stream waits on the slot's event.  The slot's previous batch was
+        // waited for before this submit could happen (at most two batches in flight), so its staging is free.
+        hipStream_t cs = s->stream0;
+        if ((rc = upload(sl.d_bases, b->bases2, b->n_bases / 4, cs))) return rc;
+        if (b->nmask && (rc = upload(sl.d_nmask, b->nmask, b->n_bases / 8, cs))) return rc;
+        if ((rc = upload(sl.d_off1, b->seg1_offset, n * 8, cs)) || (rc = upload(sl.d_len1, b->seg1_length, n * 4, cs))) return rc;
+        if (paired && ((rc = upload(sl.d_off2, b->seg2_offset, n * 8, cs)) || (rc = upload(sl.d_len2, b->seg2_length, n * 4, cs)))) return rc;
+        if (b->mean_quality && (rc = upload(sl.d_mq, b->mean_quality, n * 4, cs))) return rc;
+        if (b->compression && (rc = upload(sl.d_comp, b->compression, n * 4, cs))) return rc;
+        HIPCHK(hipEventRecord(sl.uploaded, cs));
+        HIPCHK(hipStreamWaitEvent(s->stream, sl.uploaded, 0));
+        bases = sl.d_bases.as<uint32_t>();
+        nmask = b->nmask ? sl.d_nmask.as<uint32_t>() : nullptr;
+        off1 = sl.d_off1.as<uint64_t>(); sl.len1 = sl.d_len1.as<uint32_t>();
+        off2 = paired ? sl.d_off2.as<uint64_t>() : nullptr; sl.len2 = paired ? sl.d_len2.as<uint32_t>() : nullptr;
         sl.mq = b->mean_quality ? sl.d_mq.as<float>() : nullptr;
         sl.comp = b->compression ? sl.d_comp.as<float>() : nullptr;
         sl.h_len1.assign(b->seg1_length, b->seg1_length + n);
@@ -1537,6 +1547,7 @@ extern "C" int chn_shard_finish(chn_stream *s, const uint64_t *dev_partial) {
 extern "C" int chn_stream_sync(chn_stream *s) {
     if (!s) return fail(CHN_E_INVALID, "null stream");
     HIPCHK(hipSetDevice(s->idx->d.device));
+    HIPCHK(hipStreamSynchronize(s->stream0));
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipStreamSynchronize(s->stream2));
     return CHN_OK;
@@ -1747,6 +1758,15 @@ extern "C" int chn_synth_reads(int device, uint64_t seed, const uint32_t *dev_ge
     hipLaunchKernelGGL(k_synth_reads, dim3((max_dwords + 63) / 64, gy, gz), dim3(64), 0, 0, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
+    return CHN_OK;
+}
+extern "C" int chn_host_alloc(uint64_t bytes, void **ptr) {
+    if (!ptr) return fail(CHN_E_INVALID, "null argument");
+    HIPCHK(hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return CHN_OK;
+}
+extern "C" int chn_host_free(void *ptr) {
+    if (ptr) HIPCHK(hipHostFree(ptr));
     return CHN_OK;
 }
 extern "C" int chn_device_malloc(int device, uint64_t bytes, void **ptr) {

@@ -232,6 +232,11 @@ typedef struct chn_synth_reads_out {
 int chn_synth_reads(int device, uint64_t seed, const uint32_t *dev_genomes, uint64_t n_genomes, uint64_t genome_len,
                     uint64_t first_read_id, uint64_t n_reads, uint32_t read_len_min, uint32_t read_len_max, double sub_rate,
                     double random_fraction, float mean_quality, chn_synth_reads_out *out);
+/* Page-locked host memory.  Host batches whose arrays live in such memory are uploaded asynchronously on a copy stream,
+ * so with two batches in flight the upload of batch i+1 overlaps the kernels of batch i; pageable memory works too but
+ * its copies are staged synchronously by the runtime. */
+int chn_host_alloc(uint64_t bytes, void **ptr);
+int chn_host_free(void *ptr);
 int chn_device_malloc(int device, uint64_t bytes, void **ptr);
 int chn_device_free(int device, void *ptr);
 int chn_device_upload(int device, void *dev_dst, const void *host_src, uint64_t bytes);
