@@ -72,7 +72,8 @@ def main():
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
     dev = local % ndev  # == local on a real N-GPU launch; wraps only in a gloo rehearsal on fewer GPUs
-    if world > 1:
+    use_dist = "WORLD_SIZE" in os.environ  # launched by torch.distributed.run (also with one rank: same RCCL code path)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -147,7 +148,7 @@ def main():
             nwords = e * 3 * ((B + 63) // 64)
             partial = torch.empty(max(nwords, 1), dtype=torch.int64, device=torch.device("cuda", local))
             stream.shard_probe(index, partial.data_ptr(), nwords)
-            if world > 1:
+            if use_dist:
                 if args.backend == "nccl":
                     dist.all_reduce(partial, op=dist.ReduceOp.SUM)
                 else:  # gloo rehearsal: through host memory
@@ -174,7 +175,7 @@ def main():
         return res
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -187,7 +188,7 @@ def main():
     res = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -195,7 +196,7 @@ def main():
     # summary counters (ResultSummary, include/result.hpp:18-25): the one collective of the read-sharded mode
     call = api.device_download(local, res.call, n_reads, np.uint8)
     summary = shard.summary_counts(call, ncat)
-    if world > 1 and not rows_mode:  # in rows mode every rank already holds the calls of the whole batch
+    if use_dist and not rows_mode:  # in rows mode every rank already holds the calls of the whole batch
         summary = shard.merge_summary(summary, dist, coll_dev)
 
     k1_ms, k1_n = stream.profile(0)
@@ -267,7 +268,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(api, index, reads, res, n_reads, args, local, categories, b2c)
     stream.destroy()
     index.destroy()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
