@@ -110,12 +110,42 @@ struct K1Args {
     const uint32_t *order;
     uint32_t *num_hashes, *counts, *unique;
     uint64_t *rows;          // MODE_ROWS: per-wavefront row log, entry e of wavefront g at rows[(wave_base[g] + e) * W]
-    uint8_t *row_owner;      // MODE_ROWS: owner lane (read slot in the wavefront) of every log entry
+    uint32_t *rowlog;        // MODE_ROWS: compact entry (see encode_row) of every log entry; MODE_LIST: owner lane
     const uint64_t *wave_base;
     uint32_t *wave_count;    // MODE_ROWS: entries written by wavefront g
     const uint8_t *read_bin; // MODE_EMPLACE: target bin of "read" (genome chunk) r
     uint32_t ablate;         // diagnostics only (CHN_ABLATE env): 1 = skip the gathers, 2 = skip hash+gathers
 };
+
+// Compact row-log entry: bits 0-1 number of set bins (0..3), bits 2-9 / 10-17 / 18-25 their indices, bits 26-31 the owner
+// lane.  A row with more than three set bins is rare (true bins + ~1 % false positives per bin): it is flagged by
+// count = 0 with a non-zero first index field and its W full words are stored at the same entry of the full-row buffer.
+#define ROWLOG_ESCAPE 4u  // count 0, idx0 field = 1
+template <int W>
+__device__ __forceinline__ uint32_t encode_row(const uint64_t *acc, uint32_t B, uint32_t owner, bool &escaped) {
+    uint64_t m[W];
+    uint32_t pc = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        m[w] = acc[w];
+        if (w == W - 1 && (B & 63u)) m[w] &= (1ULL << (B & 63u)) - 1;  // technical bins >= B never count
+        pc += (uint32_t)__popcll(m[w]);
+    }
+    escaped = pc > 3;
+    if (escaped) return ROWLOG_ESCAPE | (owner << 26);
+    uint32_t e = pc | (owner << 26), slot = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        uint64_t x = m[w];
+        while (x) {
+            const uint32_t b = (uint32_t)w * 64 + (uint32_t)__ffsll((long long)x) - 1;
+            x &= x - 1;
+            e |= b << (2 + 8 * slot);
+            ++slot;
+        }
+    }
+    return e;
+}
 
 template <int W>
 __device__ __forceinline__ void load_row_and(const uint64_t *p, uint64_t *acc) {
@@ -207,17 +237,21 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
                 atomicAdd(&cnt[c * WAVE + owner], 1u);
                 if (single) atomicAdd(&unq[c * WAVE + owner], 1u);
             }
-        } else {  // MODE_ROWS: append the round to the wavefront's row log -- 64 consecutive rows per round, fully coalesced
+        } else {  // MODE_ROWS / MODE_LIST: append the round to the wavefront's log -- 64 consecutive entries per round, coalesced
             if (pend_has) {
                 const uint64_t e = wbase + consumed + lane;
-                uint64_t *dst = a.rows + e * W;
-                if (W == 2) {
-                    *reinterpret_cast<ulonglong2 *>(dst) = make_ulonglong2(acc[0], acc[1]);
+                if (MODE == MODE_LIST) {
+                    a.rows[e] = acc[0];
+                    a.rowlog[e] = owner << 26;
                 } else {
+                    bool esc;
+                    a.rowlog[e] = encode_row<W>(acc, a.B, owner, esc);
+                    if (esc) {
+                        uint64_t *dst = a.rows + e * W;
 #pragma unroll
-                    for (int w = 0; w < W; ++w) dst[w] = acc[w];
+                        for (int w = 0; w < W; ++w) dst[w] = acc[w];
+                    }
                 }
-                a.row_owner[e] = (uint8_t)owner;
             }
             consumed += pend_n;
         }
@@ -405,7 +439,7 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
 // ------------------------------------------------------------------------------------------------
 struct K2Args {
     const uint64_t *rows;
-    const uint8_t *row_owner;
+    const uint32_t *rowlog;
     const uint64_t *wave_base;
     const uint32_t *wave_count;
     const uint32_t *order;
@@ -414,7 +448,7 @@ struct K2Args {
     uint8_t b2c[256];
 };
 
-#define K2_THREADS 256
+#define K2_THREADS 512
 template <int W>
 __global__ __launch_bounds__(K2_THREADS) void k_count_wavelog(const K2Args a) {
     extern __shared__ __align__(16) unsigned char smem2[];
@@ -428,24 +462,38 @@ __global__ __launch_bounds__(K2_THREADS) void k_count_wavelog(const K2Args a) {
     for (uint32_t i = tid; i < WAVE * B; i += K2_THREADS) tot[i] = 0;
     for (uint32_t i = tid; i < WAVE * C; i += K2_THREADS) { unq[i] = 0; chosen[i] = 255; }
     for (uint32_t i = tid; i < WAVE * W; i += K2_THREADS) cmask[i] = 0;
-    s_b2c[tid] = a.b2c[tid];
+    if (tid < 256) s_b2c[tid] = a.b2c[tid];
     __syncthreads();
     const uint32_t count = a.wave_count[g];
     const uint64_t base = a.wave_base[g];
     const uint64_t *rows = a.rows + base * W;
-    const uint8_t *own = a.row_owner + base;
+    const uint32_t *log = a.rowlog + base;
     const uint64_t lastmask = (B & 63u) ? ((1ULL << (B & 63u)) - 1) : ~0ULL;
-    // pass A: per-bin totals of each of the 64 reads
-    for (uint32_t e = tid; e < count; e += K2_THREADS) {
-        const uint32_t o = own[e];
+    // pass A: per-bin totals of each of the 64 reads.  Four compact entries per load: the loop is latency-bound per thread.
+    const uint4 *log4 = reinterpret_cast<const uint4 *>(log);
+    for (uint32_t i4 = tid; i4 * 4 < count; i4 += K2_THREADS) {
+        const uint4 v4 = log4[i4];
+        const uint32_t xs[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-        for (int w = 0; w < W; ++w) {
-            uint64_t x = rows[(size_t)e * W + w];
-            if (w == W - 1) x &= lastmask;
-            while (x) {
-                const uint32_t b = (uint32_t)__ffsll((long long)x) - 1;
-                x &= x - 1;
-                atomicAdd(&tot[o * B + w * 64 + b], 1u);
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t e = i4 * 4 + q;
+            if (e >= count) break;
+            const uint32_t x = xs[q], o = x >> 26, pc = x & 3u;
+            if (pc) {
+                atomicAdd(&tot[o * B + ((x >> 2) & 0xffu)], 1u);
+                if (pc > 1) atomicAdd(&tot[o * B + ((x >> 10) & 0xffu)], 1u);
+                if (pc > 2) atomicAdd(&tot[o * B + ((x >> 18) & 0xffu)], 1u);
+            } else if (x & 0x3fcu) {  // escaped: more than three set bins, full row in the side buffer
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    uint64_t r = rows[(size_t)e * W + w];
+                    if (w == W - 1) r &= lastmask;
+                    while (r) {
+                        const uint32_t b = (uint32_t)__ffsll((long long)r) - 1;
+                        r &= r - 1;
+                        atomicAdd(&tot[o * B + w * 64 + b], 1u);
+                    }
+                }
             }
         }
     }
@@ -469,16 +517,30 @@ __global__ __launch_bounds__(K2_THREADS) void k_count_wavelog(const K2Args a) {
     }
     __syncthreads();
     // pass B: a minimiser is a unique hit if exactly one category's chosen bin contains it (:121-136)
-    for (uint32_t e = tid; e < count; e += K2_THREADS) {
-        const uint32_t o = own[e];
-        uint32_t found = 0, fbin = 0;
+    for (uint32_t i4 = tid; i4 * 4 < count; i4 += K2_THREADS) {
+        const uint4 v4 = log4[i4];
+        const uint32_t xs[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-        for (int w = 0; w < W; ++w) {
-            const uint64_t x = rows[(size_t)e * W + w] & cmask[o * W + w];
-            found += (uint32_t)__popcll(x);
-            if (x) fbin = w * 64 + (uint32_t)__ffsll((long long)x) - 1;
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t e = i4 * 4 + q;
+            if (e >= count) break;
+            const uint32_t x = xs[q], o = x >> 26, pc = x & 3u;
+            uint32_t found = 0, fbin = 0;
+            if (pc) {
+                for (uint32_t j = 0; j < pc; ++j) {
+                    const uint32_t b = (x >> (2 + 8 * j)) & 0xffu;
+                    if ((cmask[o * W + (b >> 6)] >> (b & 63u)) & 1ULL) { ++found; fbin = b; }
+                }
+            } else if (x & 0x3fcu) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    const uint64_t r = rows[(size_t)e * W + w] & cmask[o * W + w];
+                    found += (uint32_t)__popcll(r);
+                    if (r) fbin = w * 64 + (uint32_t)__ffsll((long long)r) - 1;
+                }
+            }
+            if (found == 1) atomicAdd(&unq[o * C + s_b2c[fbin]], 1u);
         }
-        if (found == 1) atomicAdd(&unq[o * C + s_b2c[fbin]], 1u);
     }
     __syncthreads();
     for (uint32_t i = tid; i < WAVE * C; i += K2_THREADS) {
@@ -497,7 +559,7 @@ __global__ void k_wave_caps(const uint32_t *order, const uint32_t *len1, const u
     if (i < n) { const uint32_t r = order[i]; v = len1[r] + (len2 ? len2[r] : 0u); }
     uint64_t sum = v;
     for (int o = 32; o > 0; o >>= 1) sum += (uint64_t)__shfl_xor((long long)sum, o);
-    if (lane_id() == 0 && i < n) caps[i / WAVE] = sum;
+    if (lane_id() == 0 && i < n) caps[i / WAVE] = (sum + 3) & ~3ULL;  // log bases stay 16-byte aligned for uint4 reads of compact entries
 }
 __global__ __launch_bounds__(1024) void k_scan_u64(uint64_t *v, uint32_t n) {  // in place exclusive scan, single workgroup
     __shared__ uint64_t part[1024];
@@ -526,7 +588,9 @@ struct ShardArgs {
     uint64_t S, row_begin, row_end;
     uint32_t shift, h, W;
     uint64_t *partial;           // [entry][h][W]
-    uint64_t *rows;              // wavefront log of ANDed rows (k_and_partial)
+    uint64_t *rows;              // full-row side buffer of the wavefront log (k_and_partial, escaped rows only)
+    uint32_t *rowlog;            // compact row log (owner in bits 26-31 on entry to k_and_partial)
+    uint32_t B;
 };
 template <int W>
 __global__ __launch_bounds__(256) void k_probe_partial(const ShardArgs a) {
@@ -549,12 +613,19 @@ __global__ __launch_bounds__(256) void k_and_partial(const ShardArgs a) {
     const uint32_t g = blockIdx.x, count = a.wave_count[g];
     const uint64_t *in = a.partial + a.cbase[g] * a.h * W;
     uint64_t *rows = a.rows + a.wave_base[g] * W;
+    uint32_t *log = a.rowlog + a.wave_base[g];
     for (uint32_t e = threadIdx.x; e < count; e += blockDim.x) {
+        uint64_t acc[W];
 #pragma unroll
         for (int w = 0; w < W; ++w) {
-            uint64_t acc = ~0ULL;
-            for (uint32_t i = 0; i < a.h; ++i) acc &= in[((size_t)e * a.h + i) * W + w];
-            rows[(size_t)e * W + w] = acc;
+            acc[w] = ~0ULL;
+            for (uint32_t i = 0; i < a.h; ++i) acc[w] &= in[((size_t)e * a.h + i) * W + w];
+        }
+        bool esc;
+        log[e] = encode_row<W>(acc, a.B, log[e] >> 26, esc);
+        if (esc) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) rows[(size_t)e * W + w] = acc[w];
         }
     }
 }
@@ -1127,7 +1198,7 @@ extern "C" int chn_stream_create(chn_index *idx, const chn_stream_cfg *cfg, chn_
     const bool fused = !sharded && idx->single_bin_categories && C <= 8 && idx->d.bin_words == 1;
     if (!fused) {
         const uint64_t nw = (n + WAVE - 1) / WAVE;
-        if ((rc = s->d_rows.ensure(cfg->max_bases * idx->d.bin_words * 8)) || (rc = s->d_rowown.ensure(cfg->max_bases)) ||
+        if ((rc = s->d_rows.ensure((cfg->max_bases + 4 * nw) * idx->d.bin_words * 8)) || (rc = s->d_rowown.ensure((cfg->max_bases + 4 * nw) * 4)) ||
             (rc = s->d_wbase.ensure(nw * 8)) || (rc = s->d_wcount.ensure(nw * 4))) { chn_stream_destroy(s); return rc; }
     }
     *out = s;
@@ -1335,7 +1406,7 @@ static int submit_impl(chn_stream *s, const chn_batch *b, bool list_mode) {
     a.order = s->d_order.as<uint32_t>();
     if (const char *ab = std::getenv("CHN_ABLATE")) a.ablate = (uint32_t)std::atoi(ab);
     a.num_hashes = sl.d_num_hashes.as<uint32_t>(); a.counts = sl.d_counts.as<uint32_t>(); a.unique = sl.d_unique.as<uint32_t>();
-    a.rows = list_mode ? s->d_list.as<uint64_t>() : s->d_rows.as<uint64_t>(); a.row_owner = s->d_rowown.as<uint8_t>();
+    a.rows = list_mode ? s->d_list.as<uint64_t>() : s->d_rows.as<uint64_t>(); a.rowlog = s->d_rowown.as<uint32_t>();
     a.wave_base = s->d_wbase.as<uint64_t>(); a.wave_count = s->d_wcount.as<uint32_t>();
     const uint32_t n_waves = (uint32_t)((n + WAVE - 1) / WAVE);
     if (!fused) {
@@ -1367,7 +1438,7 @@ static int launch_tail(chn_stream *s, Slot &sl, bool fused) {
     if (!fused) {
         K2Args k2;
         std::memset(&k2, 0, sizeof(k2));
-        k2.rows = s->d_rows.as<uint64_t>(); k2.row_owner = s->d_rowown.as<uint8_t>();
+        k2.rows = s->d_rows.as<uint64_t>(); k2.rowlog = s->d_rowown.as<uint32_t>();
         k2.wave_base = s->d_wbase.as<uint64_t>(); k2.wave_count = s->d_wcount.as<uint32_t>(); k2.order = s->d_order.as<uint32_t>();
         k2.counts = sl.d_counts.as<uint32_t>(); k2.unique = sl.d_unique.as<uint32_t>();
         k2.n_reads = (uint32_t)n; k2.B = (uint32_t)d.bins; k2.C = C; k2.W = W;
@@ -1424,8 +1495,8 @@ extern "C" int chn_batch_submit(chn_stream *s, const chn_batch *b) { return subm
 static int ensure_shard_buffers(chn_stream *s) {
     const uint64_t nw = (s->cfg.max_reads + WAVE - 1) / WAVE;
     int rc;
-    if ((rc = s->d_list.ensure(s->cfg.max_bases * 8)) || (rc = s->d_cbase.ensure((nw + 1) * 8))) return rc;
-    if ((rc = s->d_rows.ensure(s->cfg.max_bases * s->idx->d.bin_words * 8)) || (rc = s->d_rowown.ensure(s->cfg.max_bases)) ||
+    if ((rc = s->d_list.ensure((s->cfg.max_bases + 4 * nw) * 8)) || (rc = s->d_cbase.ensure((nw + 1) * 8))) return rc;
+    if ((rc = s->d_rows.ensure((s->cfg.max_bases + 4 * nw) * s->idx->d.bin_words * 8)) || (rc = s->d_rowown.ensure((s->cfg.max_bases + 4 * nw) * 4)) ||
         (rc = s->d_wbase.ensure(nw * 8)) || (rc = s->d_wcount.ensure(nw * 4))) return rc;
     return CHN_OK;
 }
@@ -1436,6 +1507,7 @@ static ShardArgs shard_args(chn_stream *s, const chn_index *shard, uint64_t *par
     a.list = s->d_list.as<uint64_t>(); a.wave_base = s->d_wbase.as<uint64_t>(); a.cbase = s->d_cbase.as<uint64_t>();
     a.wave_count = s->d_wcount.as<uint32_t>(); a.words = shard->words; a.S = d.bin_size; a.row_begin = d.row_begin; a.row_end = d.row_end;
     a.shift = (uint32_t)d.hash_shift; a.h = d.hash_funs; a.W = (uint32_t)d.bin_words; a.partial = partial; a.rows = s->d_rows.as<uint64_t>();
+    a.rowlog = s->d_rowown.as<uint32_t>(); a.B = (uint32_t)d.bins;
     return a;
 }
 

@@ -125,6 +125,19 @@ def test_paired_mode_call_category(api, oracle_lib):
     oidx.free()
 
 
+def test_dense_rows_escape_path(api, oracle_lib):
+    """minimisers present in more than three bins (near-identical genomes in 6 bins, heavy background fill): the compact
+    row-log entry cannot hold them and the full-row side buffer is used"""
+    r = util.rng(71)
+    base = util.random_seq(r, 4000)
+    gs = [util.mutate(r, base, 0.002 * i) for i in range(6)] + [util.random_seq(r, 4000) for _ in range(4)]
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [0, 1, 0, 1, 0, 1, 0, 1, 0, 1], ["human", "microbial"], bin_size=7001,
+                                   fill_seed=9, fill=0.35)
+    reads = util.sample_reads(r, gs, 300, (100, 2000), sub_rate=0.01)
+    check(api, oracle_lib, oidx, reads)  # the six near-identical genomes put >= 4 set bins into most of their rows
+    oidx.free()
+
+
 def test_many_categories_paired(api, oracle_lib):
     """more than 8 categories: the general row-log path and the array-free model+call kernel (call_category is C-way)"""
     r = util.rng(17)
