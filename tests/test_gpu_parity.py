@@ -361,3 +361,53 @@ def test_long_reads(api, oracle_lib):
     gpu, orc = check(api, oracle_lib, oidx, reads)
     assert gpu["num_hashes"][0] > 20000 and gpu["conf"][0] == 255
     oidx.free()
+
+
+def test_full_size_batch_split_invariance(api, oracle_lib):
+    """BASELINE-sized inputs, size-independent property: 262 144 device-fabricated 5 kb reads against a 1 GiB 100-bin index
+    classified as ONE batch must equal the same reads classified as four batches (different wavefront grouping, different
+    row-log layout), and a 512-read sample must equal the oracle."""
+    from charon_amd import pack
+    B, S, n, L = 100, 1 << 26, 1 << 18, 5000
+    b2c = [b % 2 for b in range(B)]
+    g = api.Index(api.make_desc(B, S, b2c, 2, 0))
+    gen = api.synth_genomes(0, 43, B, 1 << 18)
+    g.synth_fill(43, 0.215)
+    g.synth_plant(gen, B, 1 << 18, list(range(B)))
+
+    def run(first, count):
+        rd = api.synth_reads(0, 42, gen, B, 1 << 18, count, L, L, 0.05, 0.1, 40.0, first_read_id=first)
+        st = api.Stream(g, count, rd.n_bases)
+        st.set_model(api.default_model(2, 0))
+        st.submit_device(count, rd.n_bases, rd.bases2, rd.seg1_offset, rd.seg1_length, rd.mean_quality, rd.compression)
+        res = st.wait_device()
+        out = dict(num_hashes=api.device_download(0, res.num_hashes, count * 4, np.uint32),
+                   counts=api.device_download(0, res.counts, count * 8, np.uint32).reshape(count, 2),
+                   unique=api.device_download(0, res.unique_counts, count * 8, np.uint32).reshape(count, 2),
+                   probs=api.device_download(0, res.probabilities, count * 16, np.float64).reshape(count, 2),
+                   call=api.device_download(0, res.call, count, np.uint8), conf=api.device_download(0, res.confidence, count, np.uint8))
+        sample = None
+        if first == 0:
+            lens = api.device_download(0, rd.seg1_length, 512 * 4, np.uint32)
+            offs = api.device_download(0, rd.seg1_offset, 512 * 8, np.uint64)
+            nb = int(offs[-1]) + 5056
+            sample = pack.unpack_reads(api.device_download(0, rd.bases2, nb // 4, np.uint32), offs, lens)
+        st.destroy()
+        for p in (rd.bases2, rd.seg1_offset, rd.seg1_length, rd.mean_quality, rd.compression):
+            api.device_free(0, p)
+        return out, sample
+
+    whole, sample = run(0, n)
+    parts = [run(i * (n // 4), n // 4)[0] for i in range(4)]
+    for key in whole:
+        cat = np.concatenate([p[key] for p in parts])
+        assert np.array_equal(whole[key], cat, equal_nan=(key == "probs")) if key == "probs" else np.array_equal(whole[key], cat), key
+    assert (whole["call"] == 0).sum() > n // 3 and (whole["call"] == 1).sum() > n // 3
+    # oracle on a sample (index words pulled back from the device)
+    oidx = oracle_lib.Index.new(B, S, b2c, ["human", "microbial"])
+    oidx.words()[:] = g.download()
+    orc = run_oracle(oidx, sample)
+    util.assert_parity({k: v[:512] for k, v in whole.items()}, orc)
+    oidx.free()
+    api.device_free(0, gen)
+    g.destroy()
