@@ -822,7 +822,12 @@ __global__ __launch_bounds__(256) void k_len_scatter(const uint32_t *len1, const
         tile[threadIdx.x] = (uint16_t)bk;
         __syncthreads();
         uint32_t rank = 0, same = 0;
-        if (i < hi) {
+        // uniform-length batches put the whole tile into one bucket: rank = thread index, no counting needed
+        const bool uniform_tile = __syncthreads_and(tile[threadIdx.x] == tile[0] && bk != 0xffffu) != 0;
+        if (uniform_tile) {
+            rank = threadIdx.x; same = 256;
+            order[cursor[bk] + rank] = i;
+        } else if (i < hi) {
             for (uint32_t j = 0; j < 256; ++j) { const bool eq = tile[j] == bk; same += eq; rank += eq && j < threadIdx.x; }
             order[cursor[bk] + rank] = i;
         }
