@@ -411,3 +411,23 @@ def test_full_size_batch_split_invariance(api, oracle_lib):
     oidx.free()
     api.device_free(0, gen)
     g.destroy()
+
+
+def test_hash_function_counts_and_long_windows(api, oracle_lib):
+    """h = 1, 2, 4, 5 hash functions (seqan3 allows 1..5) and windows long enough to need the > 64 KB dynamic-LDS path"""
+    r = util.rng(123)
+    for nhash in (1, 2, 4, 5):
+        gs = [util.random_seq(r, 3000) for _ in range(3)]
+        mins = [np.unique(oracle_lib.minimisers(g.decode())) for g in gs]
+        oidx = oracle_lib.Index.new(3, 30011, [0, 1, 0], ["host", "bug"], nhash=nhash)
+        for b, m in enumerate(mins):
+            oidx.emplace_many(m, b)
+        assert oidx.hash_funs == nhash
+        check(api, oracle_lib, oidx, util.sample_reads(r, gs, 150, (50, 1500), sub_rate=0.03))
+        oidx.free()
+    for k, w in ((20, 140), (27, 255), (5, 200)):
+        gs = [util.random_seq(r, 4000), util.random_seq(r, 4000)]
+        oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [0, 1], ["host", "bug"], k=k, w=w, bin_size=10007)
+        reads = util.sample_reads(r, gs, 130, (1, 3000), sub_rate=0.02) + [b"A" * 700, b"ACGT" * 200, gs[0][:w], gs[0][:w - 1], gs[1][:k]]
+        check(api, oracle_lib, oidx, reads)
+        oidx.free()
