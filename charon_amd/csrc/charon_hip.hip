@@ -30,6 +30,7 @@
 #include <limits>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "charon_hip.h"
@@ -200,35 +201,40 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
     const uint64_t INV5 = 0xCCCCCCCCCCCCCCCDULL;  // 5^-1 mod 2^64 (exact division of the reverse strand)
     uint32_t my_emitted = 0;                      // == ReadEntry::num_hashes_ (include/read_entry.hpp:89)
     uint32_t qhead = 0, qcount = 0;               // wave-uniform queue state
-    // in-flight probe round
-    uint64_t pend[5][W];
-    uint32_t pend_meta = 0;
-    bool pend_has = false;   // per lane
-    bool pending = false;    // wave-uniform
+    // One probe round in flight per wavefront.  (Two rounds were tried: hipcc guards every consume and every 64-base chunk
+    // boundary with s_waitcnt vmcnt(0), which drains ALL outstanding gathers, so a second round never stays in flight and
+    // only costs ~90 VGPRs.  Counted vmcnt(N) waits would need every VMEM operation of the kernel in inline asm.)
+    struct Pend {
+        uint64_t w[5][W];
+        uint32_t meta = 0;     // owner lane | per-read index << 6
+        uint32_t n = 0;        // entries of the round (wave-uniform)
+        bool has = false;      // per lane
+        bool pending = false;  // wave-uniform
+    };
+    Pend p0;
     uint32_t consumed = 0;   // MODE_ROWS: log entries written so far (wave-uniform)
-    uint32_t pend_n = 0;     // entries of the round in flight (wave-uniform)
     const uint64_t wbase = (MODE == MODE_ROWS || MODE == MODE_LIST) ? a.wave_base[blockIdx.x] : 0;
 
-    auto probe_consume = [&]() {
-        if (MODE == MODE_EMPLACE) { pending = false; return; }
+    auto probe_consume = [&](Pend &P) {
+        if (MODE == MODE_EMPLACE) { P.pending = false; return; }
         uint64_t acc[W];
 #pragma unroll
         for (int w = 0; w < W; ++w) acc[w] = ~0ULL;
-        if (pend_has) {
+        if (P.has) {
             if (MODE == MODE_LIST) {
-                acc[0] = pend[0][0];
+                acc[0] = P.w[0][0];
             } else {
 #pragma unroll
                 for (uint32_t i = 0; i < 5; ++i)
                     if (i < a.h) {
 #pragma unroll
-                        for (int w = 0; w < W; ++w) acc[w] &= pend[i][w];
+                        for (int w = 0; w < W; ++w) acc[w] &= P.w[i][w];
                     }
             }
         }
-        const uint32_t owner = pend_meta & 63u;
+        const uint32_t owner = P.meta & 63u;
         if (MODE == MODE_FUSED) {
-            uint64_t m = pend_has ? (acc[0] & ((a.B >= 64) ? ~0ULL : ((1ULL << a.B) - 1))) : 0;
+            uint64_t m = P.has ? (acc[0] & ((a.B >= 64) ? ~0ULL : ((1ULL << a.B) - 1))) : 0;
             const bool single = __popcll(m) == 1;
             while (m) {
                 const uint32_t b = (uint32_t)__ffsll((long long)m) - 1;
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
                 if (single) atomicAdd(&unq[c * WAVE + owner], 1u);
             }
         } else {  // MODE_ROWS / MODE_LIST: append the round to the wavefront's log -- 64 consecutive entries per round, coalesced
-            if (pend_has) {
+            if (P.has) {
                 const uint64_t e = wbase + consumed + lane;
                 if (MODE == MODE_LIST) {
                     a.rows[e] = acc[0];
@@ -253,12 +259,12 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
                     }
                 }
             }
-            consumed += pend_n;
+            consumed += P.n;
         }
-        pending = false;
+        P.pending = false;
     };
 
-    auto probe_issue = [&](uint32_t n_take) {
+    auto probe_issue = [&](Pend &P, uint32_t n_take) {
         __syncthreads();
         const bool has = lane < n_take;
         const uint32_t slot = (qhead + lane) & (QCAP - 1);
@@ -274,11 +280,11 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
                 }
             }
         } else {
-            pend_has = has;
-            pend_meta = meta;
-            pend_n = n_take;
+            P.has = has;
+            P.meta = meta;
+            P.n = n_take;
             if (MODE == MODE_LIST) {
-                if (has) pend[0][0] = val;
+                if (has) P.w[0][0] = val;
             } else if (has) {
                 uint64_t rows_[5];
 #pragma unroll
@@ -287,38 +293,131 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
 #pragma unroll
                 for (uint32_t i = 0; i < 5; ++i)
                     if (i < a.h) {
-                        if (a.ablate) { pend[i][0] = rows_[i]; for (int w = 1; w < W; ++w) pend[i][w] = val; continue; }
+                        if (a.ablate) { P.w[i][0] = rows_[i]; for (int w = 1; w < W; ++w) P.w[i][w] = val; continue; }
                         const uint64_t *p = a.words + (rows_[i] - a.row_begin) * W;
                         // non-temporal: a probed line is never reused, keep it from displacing the row/base lines in L2
                         if (W == 1) {
-                            pend[i][0] = __builtin_nontemporal_load(p);
+                            P.w[i][0] = __builtin_nontemporal_load(p);
                         } else if (W == 2) {
-                            pend[i][0] = __builtin_nontemporal_load(p); pend[i][W > 1 ? 1 : 0] = __builtin_nontemporal_load(p + 1);
+                            P.w[i][0] = __builtin_nontemporal_load(p); P.w[i][W > 1 ? 1 : 0] = __builtin_nontemporal_load(p + 1);
                         } else if (W == 3) {
-                            pend[i][0] = __builtin_nontemporal_load(p); pend[i][W > 1 ? 1 : 0] = __builtin_nontemporal_load(p + 1);
-                            pend[i][W > 2 ? 2 : 0] = __builtin_nontemporal_load(p + 2);
+                            P.w[i][0] = __builtin_nontemporal_load(p); P.w[i][W > 1 ? 1 : 0] = __builtin_nontemporal_load(p + 1);
+                            P.w[i][W > 2 ? 2 : 0] = __builtin_nontemporal_load(p + 2);
                         } else {
-                            pend[i][0] = __builtin_nontemporal_load(p); pend[i][W > 1 ? 1 : 0] = __builtin_nontemporal_load(p + 1);
-                            pend[i][W > 2 ? 2 : 0] = __builtin_nontemporal_load(p + 2); pend[i][W > 3 ? 3 : 0] = __builtin_nontemporal_load(p + 3);
+                            P.w[i][0] = __builtin_nontemporal_load(p); P.w[i][W > 1 ? 1 : 0] = __builtin_nontemporal_load(p + 1);
+                            P.w[i][W > 2 ? 2 : 0] = __builtin_nontemporal_load(p + 2); P.w[i][W > 3 ? 3 : 0] = __builtin_nontemporal_load(p + 3);
                         }
                     }
             }
-            pending = true;
+            P.pending = true;
         }
         qhead = (qhead + n_take) & (QCAP - 1);
         qcount -= n_take;
         __syncthreads();
     };
 
+    // one probe turn: retire the round in flight (issued ~11 bases ago), then issue the next one
+    auto probe_turn = [&](uint32_t n_take) {
+        if (p0.pending) probe_consume(p0);
+        probe_issue(p0, n_take);
+    };
+
+    // per-segment rolling state (hoisted so that the step body below can be one generic lambda)
+    uint64_t fwd = 0, rc = 0, hist2 = 0, mv = 0, pv = 0;
+    uint32_t histn = 0, q = 0, pq = 0;
+    uint32_t t = 0, blk = 0;  // wave-uniform: offset of the newest value in its block, start index of that block
+    uint32_t L = 0;
+    bool has_nmask = false;
+
+    // One base step.  STEADY: i >= k + wn and every lane is active (compile-time tag: the start-up, first-window, short-read
+    // and activity checks disappear).  HASN: the batch carries an N mask.
+    auto step = [&](auto STEADY, auto HASN, const uint32_t i, const uint32_t j, const uint32_t cur, const uint32_t ncur) {
+        constexpr bool kSteady = decltype(STEADY)::value, kHasN = decltype(HASN)::value;
+        const bool act = kSteady || i < L;
+        bool emit = false;
+        const bool have_value = kSteady || i + 1 >= k;  // wave-uniform
+        if (act) {
+            const uint32_t code = (cur >> (j * 2)) & 3u;
+            const uint32_t nf = (kHasN && has_nmask) ? ((ncur >> (i & 31u)) & 1u) : 0u;
+            // dna5 ranks A0 C1 G2 N3 T4; complement table [4,2,1,3,0]
+            const uint32_t d_in = nf ? 3u : code + (code == 3u);
+            const uint32_t cd_in = nf ? 3u : (3u - code) + (code == 0u);
+            uint32_t d_out = 0, cd_out = 0;
+            if (kSteady || i >= k) {
+                const uint32_t oc = (uint32_t)(hist2 >> (2 * (k - 1))) & 3u;
+                const uint32_t on = kHasN ? ((histn >> (k - 1)) & 1u) : 0u;
+                d_out = on ? 3u : oc + (oc == 3u);
+                cd_out = on ? 3u : (3u - oc) + (oc == 0u);
+            }
+            hist2 = (hist2 << 2) | code;
+            if (kHasN) histn = (histn << 1) | nf;
+            fwd = (fwd - (uint64_t)d_out * a.powk1) * 5u + d_in;
+            rc = (rc - cd_out) * INV5 + (uint64_t)cd_in * a.powk1;
+            if (have_value) {
+                const uint32_t p = i + 1 - k;  // index of this canonical value (== blk + t)
+                const uint64_t vf = fwd ^ a.seed, vr = rc ^ a.seed;
+                const uint64_t v = vf < vr ? vf : vr;
+                // running rightmost minimum of the current block's prefix [blk, p]
+                if (t == 0 || v <= pv) { pv = v; pq = p; }
+                if (!kSteady && p < wn) {  // first window: its rightmost minimum is the prefix minimum of block 0
+                    mv = pv; q = pq;
+                    emit = (p == wn - 1);
+                } else if (q + wn == p) {  // tracked minimum left the window: rightmost minimum of the new one
+                    mv = pv; q = pq;
+                    if (t + 1 < wn) {
+                        const uint64_t sv = ring[(t + 1) * WAVE + lane];
+                        if (sv < pv) { mv = sv; q = blk - wn + spos[(t + 1) * WAVE + lane]; }
+                    }
+                    emit = true;
+                } else if (v < mv) {
+                    mv = v; q = p; emit = true;
+                }
+                ring[t * WAVE + lane] = v;
+                // sequence shorter than one window: a single minimiser over all its values
+                if (!kSteady && i + 1 == L && p + 1 < wn) emit = true;
+            }
+        }
+        if (have_value) {
+            if (t + 1 == wn) {
+                // block end: turn the raw values of this block into rightmost suffix minima, in place
+                uint64_t sv = ring[(wn - 1) * WAVE + lane];
+                uint32_t sp = wn - 1;
+                spos[(wn - 1) * WAVE + lane] = (uint8_t)sp;
+#pragma unroll
+                for (int u = (int)wn - 2; u >= 1; --u) {
+                    const uint64_t x = ring[u * WAVE + lane];
+                    if (x < sv) { sv = x; sp = (uint32_t)u; }
+                    ring[u * WAVE + lane] = sv;
+                    spos[u * WAVE + lane] = (uint8_t)sp;
+                }
+                t = 0; blk += wn;
+            } else {
+                ++t;
+            }
+        }
+        const uint64_t mask = __ballot(emit);
+        if (mask) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (emit) {
+                const uint32_t pos = (qhead + qcount + rank) & (QCAP - 1);
+                qv[pos] = mv;
+                qm[pos] = lane | (my_emitted << 6);
+                ++my_emitted;
+            }
+            qcount += (uint32_t)__popcll(mask);
+            if (qcount >= WAVE) probe_turn(WAVE);
+        }
+    };
+
     for (uint32_t s = 0; s < a.nseg; ++s) {
-        const uint32_t L = valid ? (s == 0 ? a.len1[r] : a.len2[r]) : 0;
+        L = valid ? (s == 0 ? a.len1[r] : a.len2[r]) : 0;
         const uint64_t off = valid ? (s == 0 ? a.off1[r] : a.off2[r]) : 0;
         const uint32_t maxL = wave_max_u32(L);
+        const uint32_t minL = ~wave_max_u32(~L);  // lanes past the end of the batch have L = 0 and force the generic body
         const uint4 *bp = reinterpret_cast<const uint4 *>(a.bases + (off >> 4));   // 64 bases per uint4
         const uint2 *np = a.nmask ? reinterpret_cast<const uint2 *>(a.nmask + (off >> 5)) : nullptr;
-        uint64_t fwd = 0, rc = 0, hist2 = 0, mv = 0, pv = 0;
-        uint32_t histn = 0, q = 0, pq = 0;
-        uint32_t t = 0, blk = 0;  // wave-uniform: offset of the newest value in its block, start index of that block
+        has_nmask = np != nullptr;
+        fwd = 0; rc = 0; hist2 = 0; mv = 0; pv = 0; histn = 0; q = 0; pq = 0; t = 0; blk = 0;
 
         const uint32_t nchunk = (maxL + 63) >> 6;
         uint4 wnext = make_uint4(0, 0, 0, 0);
@@ -334,91 +433,21 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
                 const uint32_t ibase = c * 64 + dd * 16;
                 if (ibase >= maxL) break;
                 const uint32_t jn = maxL - ibase < 16 ? maxL - ibase : 16;
-                for (uint32_t j = 0; j < jn; ++j) {
-                    const uint32_t i = ibase + j;
-                    const bool act = i < L;
-                    bool emit = false;
-                    const bool have_value = i + 1 >= k;  // wave-uniform
-                    if (act) {
-                        const uint32_t code = (cur >> (j * 2)) & 3u;
-                        const uint32_t nf = np ? ((ncur >> (i & 31u)) & 1u) : 0u;
-                        // dna5 ranks A0 C1 G2 N3 T4; complement table [4,2,1,3,0]
-                        const uint32_t d_in = nf ? 3u : code + (code == 3u);
-                        const uint32_t cd_in = nf ? 3u : (3u - code) + (code == 0u);
-                        uint32_t d_out = 0, cd_out = 0;
-                        if (i >= k) {
-                            const uint32_t oc = (uint32_t)(hist2 >> (2 * (k - 1))) & 3u;
-                            const uint32_t on = (histn >> (k - 1)) & 1u;
-                            d_out = on ? 3u : oc + (oc == 3u);
-                            cd_out = on ? 3u : (3u - oc) + (oc == 0u);
-                        }
-                        hist2 = (hist2 << 2) | code;
-                        histn = (histn << 1) | nf;
-                        fwd = (fwd - (uint64_t)d_out * a.powk1) * 5u + d_in;
-                        rc = (rc - cd_out) * INV5 + (uint64_t)cd_in * a.powk1;
-                        if (have_value) {
-                            const uint32_t p = i + 1 - k;  // index of this canonical value (== blk + t)
-                            const uint64_t vf = fwd ^ a.seed, vr = rc ^ a.seed;
-                            const uint64_t v = vf < vr ? vf : vr;
-                            // running rightmost minimum of the current block's prefix [blk, p]
-                            if (t == 0 || v <= pv) { pv = v; pq = p; }
-                            if (p < wn) {  // first window: its rightmost minimum is the prefix minimum of block 0
-                                mv = pv; q = pq;
-                                emit = (p == wn - 1);
-                            } else if (q + wn == p) {  // tracked minimum left the window: rightmost minimum of the new one
-                                mv = pv; q = pq;
-                                if (t + 1 < wn) {
-                                    const uint64_t sv = ring[(t + 1) * WAVE + lane];
-                                    if (sv < pv) { mv = sv; q = blk - wn + spos[(t + 1) * WAVE + lane]; }
-                                }
-                                emit = true;
-                            } else if (v < mv) {
-                                mv = v; q = p; emit = true;
-                            }
-                            ring[t * WAVE + lane] = v;
-                            // sequence shorter than one window: a single minimiser over all its values
-                            if (i + 1 == L && p + 1 < wn) emit = true;
-                        }
-                    }
-                    if (have_value) {
-                        if (t + 1 == wn) {
-                            // block end: turn the raw values of this block into rightmost suffix minima, in place
-                            uint64_t sv = ring[(wn - 1) * WAVE + lane];
-                            uint32_t sp = wn - 1;
-                            spos[(wn - 1) * WAVE + lane] = (uint8_t)sp;
-#pragma unroll
-                            for (int u = (int)wn - 2; u >= 1; --u) {
-                                const uint64_t x = ring[u * WAVE + lane];
-                                if (x < sv) { sv = x; sp = (uint32_t)u; }
-                                ring[u * WAVE + lane] = sv;
-                                spos[u * WAVE + lane] = (uint8_t)sp;
-                            }
-                            t = 0; blk += wn;
-                        } else {
-                            ++t;
-                        }
-                    }
-                    const uint64_t mask = __ballot(emit);
-                    if (mask) {
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                        if (emit) {
-                            const uint32_t pos = (qhead + qcount + rank) & (QCAP - 1);
-                            qv[pos] = mv;
-                            qm[pos] = lane | (my_emitted << 6);
-                            ++my_emitted;
-                        }
-                        qcount += (uint32_t)__popcll(mask);
-                        if (qcount >= WAVE) {
-                            if (pending) probe_consume();
-                            probe_issue(WAVE);
-                        }
-                    }
+                // Steady-state dword: every lane still has all 16 bases, and all of them lie past the warm-up and the first
+                // window, so the specialised body drops the activity predicate and the start-up / short-read cases.
+                const bool steady = ibase >= k + wn && ibase + 16 <= minL;
+                if (steady && !np) {
+                    for (uint32_t j = 0; j < 16; ++j) step(std::true_type(), std::false_type(), ibase + j, j, cur, ncur);
+                } else if (steady) {
+                    for (uint32_t j = 0; j < 16; ++j) step(std::true_type(), std::true_type(), ibase + j, j, cur, ncur);
+                } else {
+                    for (uint32_t j = 0; j < jn; ++j) step(std::false_type(), std::true_type(), ibase + j, j, cur, ncur);
                 }
             }
         }
     }
-    if (pending) probe_consume();
-    if (qcount) { probe_issue(qcount); if (pending) probe_consume(); }
+    if (qcount) probe_turn(qcount);
+    if (p0.pending) probe_consume(p0);
 
     __syncthreads();
     if ((MODE == MODE_ROWS || MODE == MODE_LIST) && lane == 0) a.wave_count[blockIdx.x] = consumed;
