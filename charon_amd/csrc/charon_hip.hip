@@ -78,6 +78,21 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
     return v;
 }
 
+// Loads whose completion the KERNEL tracks instead of the compiler (cdna_hip_programming.md 5.7): hipcc does not see a
+// load inside an asm statement, so it inserts no s_waitcnt for it -- the caller must wait before touching the result.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x4_t asm_load_b128(const void *p) {
+    u32x4_t v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ u32x2_t asm_load_b64(const void *p) {
+    u32x2_t v;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
 // seqan3 interleaved_bloom_filter::hash_and_fit (fastrange), SURVEY App. A.3
 __device__ __forceinline__ uint64_t hash_and_fit_row(uint64_t x, uint64_t seed, uint64_t S, uint32_t shift) {
     x *= seed;
@@ -212,11 +227,15 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
         bool pending = false;  // wave-uniform
     };
     Pend p0;
+    bool base_ready = true;  // wave-uniform: no untracked (asm) base prefetch is outstanding
     uint32_t consumed = 0;   // MODE_ROWS: log entries written so far (wave-uniform)
     const uint64_t wbase = (MODE == MODE_ROWS || MODE == MODE_LIST) ? a.wave_base[blockIdx.x] : 0;
 
     auto probe_consume = [&](Pend &P) {
         if (MODE == MODE_EMPLACE) { P.pending = false; return; }
+        // the round's gathers are needed now; this full wait also completes the base prefetch issued before them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        base_ready = true;
         uint64_t acc[W];
 #pragma unroll
         for (int w = 0; w < W; ++w) acc[w] = ~0ULL;
@@ -293,7 +312,7 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
 #pragma unroll
                 for (uint32_t i = 0; i < 5; ++i)
                     if (i < a.h) {
-                        if (a.ablate) { P.w[i][0] = rows_[i]; for (int w = 1; w < W; ++w) P.w[i][w] = val; continue; }
+                        if (a.ablate & 3u) { P.w[i][0] = rows_[i]; for (int w = 1; w < W; ++w) P.w[i][w] = val; continue; }
                         const uint64_t *p = a.words + (rows_[i] - a.row_begin) * W;
                         // non-temporal: a probed line is never reused, keep it from displacing the row/base lines in L2
                         if (W == 1) {
@@ -420,13 +439,22 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
         fwd = 0; rc = 0; hist2 = 0; mv = 0; pv = 0; histn = 0; q = 0; pq = 0; t = 0; blk = 0;
 
         const uint32_t nchunk = (maxL + 63) >> 6;
-        uint4 wnext = make_uint4(0, 0, 0, 0);
-        uint2 nnext = make_uint2(0, 0);
-        if (L > 0) { wnext = bp[0]; if (np) nnext = np[0]; }
+        // Bases are prefetched one 64-base chunk ahead through asm loads.  hipcc would guard their use with s_waitcnt
+        // vmcnt(0) at every chunk boundary and thereby drain the probe round in flight; instead the kernel knows that any
+        // probe consume since the prefetch has already waited for it (base_ready) and only waits when none happened.
+        u32x4_t wnext = {0u, 0u, 0u, 0u};
+        u32x2_t nnext = {0u, 0u};
+        if (L > 0) { wnext = asm_load_b128(bp); if (np) nnext = asm_load_b64(np); }
+        base_ready = false;
         for (uint32_t c = 0; c < nchunk; ++c) {
-            const uint4 wcur = wnext;
-            const uint2 ncur2 = nnext;
-            if ((c + 1) * 64 < L) { wnext = bp[c + 1]; if (np) nnext = np[c + 1]; }
+            if (!base_ready || (a.ablate & 4u)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); base_ready = true; }  // bit 2: A/B diagnostic
+            asm volatile("" : "+v"(wnext), "+v"(nnext));  // the values are read only after the wait above
+            const uint4 wcur = make_uint4(wnext.x, wnext.y, wnext.z, wnext.w);
+            const uint2 ncur2 = make_uint2(nnext.x, nnext.y);
+            if ((c + 1) * 64 < maxL) {
+                if ((c + 1) * 64 < L) { wnext = asm_load_b128(bp + c + 1); if (np) nnext = asm_load_b64(np + c + 1); }
+                base_ready = false;
+            }
             for (uint32_t dd = 0; dd < 4; ++dd) {
                 const uint32_t cur = dd == 0 ? wcur.x : dd == 1 ? wcur.y : dd == 2 ? wcur.z : wcur.w;
                 const uint32_t ncur = dd < 2 ? ncur2.x : ncur2.y;
