@@ -64,7 +64,7 @@ EXPORTS = ["chn_index_create", "chn_index_upload_rows", "chn_index_device_words"
            "chn_model_set", "chn_batch_submit", "chn_batch_wait", "chn_stream_sync", "chn_classify_counts", "chn_stream_profile",
            "chn_stream_last_batch_bytes", "chn_synth_genomes", "chn_synth_fill_index", "chn_synth_plant", "chn_synth_reads",
            "chn_device_free", "chn_device_download", "chn_device_malloc", "chn_device_upload", "chn_host_alloc", "chn_host_free", "chn_shard_minimise",
-           "chn_shard_probe", "chn_shard_finish", "chn_minimisers", "chn_index_emplace", "chn_last_error", "chn_version"]
+           "chn_shard_probe", "chn_shard_finish", "chn_minimisers", "chn_index_emplace", "chn_index_decode_ef", "chn_index_bin_popcounts", "chn_last_error", "chn_version"]
 
 _L.chn_last_error.restype = C.c_char_p
 _L.chn_version.restype = C.c_char_p
@@ -99,6 +99,9 @@ _L.chn_shard_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
 _L.chn_shard_finish.argtypes = [C.c_void_p, C.c_void_p]
 _L.chn_minimisers.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
 _L.chn_index_emplace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+_L.chn_index_decode_ef.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64,
+                                   C.POINTER(C.c_uint64)]
+_L.chn_index_bin_popcounts.argtypes = [C.c_void_p, C.c_void_p]
 _L.chn_device_download.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
 
 
@@ -167,6 +170,34 @@ class Index:
         p, n = C.c_void_p(), C.c_uint64()
         _chk(_L.chn_index_device_words(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def decode_ef(self, m_size, wl, high, high_bits, low, slice_words=1 << 20):
+        """decode a whole sd_vector (numpy uint64 arrays `high` with `high_bits` valid bits, `low` packed wl-bit elements) on the
+        device in slices of `slice_words` words of m_high; returns the number of ill-placed bits (0 for a well-formed vector)"""
+        high = np.ascontiguousarray(high, np.uint64)
+        low = np.ascontiguousarray(low, np.uint64)
+        n_high = (high_bits + 63) // 64
+        ones_before, bad_total = 0, 0
+        for w0 in range(0, n_high, slice_words):
+            hs = high[w0:min(n_high, w0 + slice_words)]
+            ones = int(sum(bin(int(x)).count("1") for x in hs)) if hs.size < 4096 else int(np.unpackbits(hs.view(np.uint8)).sum())
+            if ones == 0:
+                continue
+            elem0 = ones_before & ~63  # a multiple of 64 elements starts on a word boundary whatever wl is
+            lw0 = elem0 * wl // 64
+            lw1 = ((ones_before + ones) * wl + 63) // 64
+            ls = low[lw0:min(low.size, lw1)]
+            bad = C.c_uint64()
+            _chk(_L.chn_index_decode_ef(self.h, m_size, wl, hs.ctypes.data, w0 * 64, hs.size, ones_before, ls.ctypes.data if ls.size else None,
+                                        elem0, ls.size, C.byref(bad)))
+            bad_total += bad.value
+            ones_before += ones
+        return bad_total
+
+    def bin_popcounts(self):
+        out = np.zeros(self.desc.technical_bins, np.uint64)
+        _chk(_L.chn_index_bin_popcounts(self.h, out.ctypes.data))
+        return out
 
     def emplace(self, values, bin_index):
         values = np.ascontiguousarray(values, dtype=np.uint64)

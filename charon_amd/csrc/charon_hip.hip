@@ -907,6 +907,78 @@ __global__ void k_batch_bytes(const uint32_t *len1, const uint32_t *len2, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Elias-Fano decode on the device (loader)
+// ------------------------------------------------------------------------------------------------
+struct EfArgs {
+    const uint64_t *high, *low;
+    uint64_t n_high_words, high_bit0, ones_before, low_elem0, m_size, row_begin, row_end;
+    uint64_t *words;
+    unsigned long long *bad;
+    uint32_t wl, W, B, TB;
+};
+__global__ __launch_bounds__(256) void k_ef_block_counts(const uint64_t *high, uint64_t n, uint32_t *block_ones) {
+    __shared__ uint32_t s[256];
+    const uint64_t i = blockIdx.x * 256ull + threadIdx.x;
+    s[threadIdx.x] = i < n ? (uint32_t)__popcll(high[i]) : 0u;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) block_ones[blockIdx.x] = s[0];
+}
+__global__ __launch_bounds__(256) void k_ef_decode(const EfArgs a, const uint64_t *block_prefix /* exclusive, per 256-word block */) {
+    __shared__ uint32_t s[256];
+    const uint64_t i = blockIdx.x * 256ull + threadIdx.x;
+    const uint64_t word = i < a.n_high_words ? a.high[i] : 0ULL;
+    const uint32_t pc = (uint32_t)__popcll(word);
+    s[threadIdx.x] = pc;
+    __syncthreads();
+    // exclusive scan of the 256 popcounts (Hillis-Steele)
+    for (int o = 1; o < 256; o <<= 1) {
+        const uint32_t v = (int)threadIdx.x >= o ? s[threadIdx.x - o] : 0u;
+        __syncthreads();
+        s[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint64_t k = a.ones_before + block_prefix[blockIdx.x] + (s[threadIdx.x] - pc);  // rank of this word's first one
+    uint64_t x = word;
+    const uint64_t bit0 = a.high_bit0 + i * 64;
+    const uint64_t lowmask = a.wl >= 64 ? ~0ULL : ((1ULL << a.wl) - 1);
+    while (x) {
+        const uint32_t j = (uint32_t)__ffsll((long long)x) - 1;
+        x &= x - 1;
+        const uint64_t z = bit0 + j - k;  // zeros before this one = its high part
+        uint64_t lo = 0;
+        if (a.wl) {
+            const uint64_t bit = (k - a.low_elem0) * a.wl, wd = bit >> 6, sh = bit & 63;
+            lo = a.low[wd] >> sh;
+            if (sh + a.wl > 64) lo |= a.low[wd + 1] << (64 - sh);
+            lo &= lowmask;
+        }
+        const uint64_t pos = (a.wl >= 64 ? 0 : (z << a.wl)) | lo;
+        ++k;
+        if (pos >= a.m_size) { atomicAdd(a.bad, 1ULL); continue; }
+        const uint64_t row = pos / a.TB;
+        const uint32_t bin = (uint32_t)(pos % a.TB);
+        if (bin >= a.B) { atomicAdd(a.bad, 1ULL); continue; }
+        if (row < a.row_begin || row >= a.row_end) continue;
+        atomicOr((unsigned long long *)&a.words[(row - a.row_begin) * a.W + (bin >> 6)], 1ULL << (bin & 63));
+    }
+}
+__global__ __launch_bounds__(256) void k_bin_popcounts(const uint64_t *words, uint64_t n_rows, uint32_t W, unsigned long long *out /* [W*64] */) {
+    __shared__ uint32_t s[256];
+    s[threadIdx.x] = 0;
+    __syncthreads();
+    // thread = (word index within row, bit): W*64 <= 256 counters per block; rows strided over blocks
+    const uint32_t tb = W * 64;
+    for (uint64_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        if (threadIdx.x < tb) s[threadIdx.x] += (uint32_t)((words[r * W + (threadIdx.x >> 6)] >> (threadIdx.x & 63)) & 1ULL);
+        if ((r / gridDim.x) % 1048576 == 1048575) {  // spill before the 32-bit counters could overflow
+            if (threadIdx.x < tb) { atomicAdd(&out[threadIdx.x], (unsigned long long)s[threadIdx.x]); s[threadIdx.x] = 0; }
+        }
+    }
+    if (threadIdx.x < tb) atomicAdd(&out[threadIdx.x], (unsigned long long)s[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // synthetic workload kernels
 // ------------------------------------------------------------------------------------------------
 __global__ void k_synth_genomes(uint32_t *out, uint64_t n_dwords, uint64_t seed) {
@@ -1124,6 +1196,71 @@ extern "C" int chn_index_download_rows(chn_index *idx, uint64_t row_begin, uint6
     HIPCHK(hipMemcpy(host_words, idx->words + (row_begin - idx->d.row_begin) * idx->d.bin_words, n_rows * idx->d.bin_words * 8, hipMemcpyDeviceToHost));
     return CHN_OK;
 }
+extern "C" int chn_index_decode_ef(chn_index *idx, uint64_t m_size, uint32_t wl, const uint64_t *high, uint64_t high_bit0, uint64_t n_high_words,
+                                   uint64_t ones_before, const uint64_t *low, uint64_t low_elem0, uint64_t n_low_words, uint64_t *bad_bits) {
+    if (!idx || !high || (wl && !low) || !bad_bits) return fail(CHN_E_INVALID, "chn_index_decode_ef: null argument");
+    if ((high_bit0 & 63) || wl > 64 || low_elem0 > ones_before) return fail(CHN_E_INVALID, "chn_index_decode_ef: bad slice description");
+    const chn_index_desc &d = idx->d;
+    if (m_size != d.technical_bins * d.bin_size) return fail(CHN_E_INVALID, "chn_index_decode_ef: m_size != technical_bins * bin_size");
+    if (n_high_words == 0) return CHN_OK;
+    if (n_high_words > (1ULL << 31)) return fail(CHN_E_INVALID, "chn_index_decode_ef: slice too large (at most 2^31 words)");
+    HIPCHK(hipSetDevice(d.device));
+    const uint64_t n_blocks = (n_high_words + 255) / 256;
+    uint64_t *d_high = nullptr, *d_low = nullptr, *d_prefix = nullptr;
+    uint32_t *d_counts = nullptr;
+    unsigned long long *d_bad = nullptr;
+    hipError_t e = hipMalloc((void **)&d_high, n_high_words * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_low, (n_low_words + 2) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_counts, n_blocks * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_prefix, n_blocks * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_bad, 8);
+    if (e == hipSuccess) e = hipMemcpy(d_high, high, n_high_words * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_low, 0, (n_low_words + 2) * 8);
+    if (e == hipSuccess && n_low_words) e = hipMemcpy(d_low, low, n_low_words * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_bad, 0, 8);
+    std::vector<uint32_t> counts(n_blocks);
+    std::vector<uint64_t> prefix(n_blocks);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_ef_block_counts, dim3((uint32_t)n_blocks), dim3(256), 0, 0, d_high, n_high_words, d_counts);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(counts.data(), d_counts, n_blocks * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) {
+        uint64_t run = 0;
+        for (uint64_t b = 0; b < n_blocks; ++b) { prefix[b] = run; run += counts[b]; }
+        e = hipMemcpy(d_prefix, prefix.data(), n_blocks * 8, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) {
+        EfArgs a;
+        a.high = d_high; a.low = d_low; a.n_high_words = n_high_words; a.high_bit0 = high_bit0; a.ones_before = ones_before; a.low_elem0 = low_elem0;
+        a.m_size = m_size; a.row_begin = d.row_begin; a.row_end = d.row_end; a.words = idx->words; a.bad = d_bad; a.wl = wl;
+        a.W = (uint32_t)d.bin_words; a.B = (uint32_t)d.bins; a.TB = (uint32_t)d.technical_bins;
+        hipLaunchKernelGGL(k_ef_decode, dim3((uint32_t)n_blocks), dim3(256), 0, 0, a, d_prefix);
+        e = hipGetLastError();
+    }
+    unsigned long long bad = 0;
+    if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_high); (void)hipFree(d_low); (void)hipFree(d_counts); (void)hipFree(d_prefix); (void)hipFree(d_bad);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? CHN_E_NOMEM : CHN_E_HIP, std::string("chn_index_decode_ef: ") + hipGetErrorString(e));
+    *bad_bits = bad;
+    return CHN_OK;
+}
+
+extern "C" int chn_index_bin_popcounts(chn_index *idx, uint64_t *out) {
+    if (!idx || !out) return fail(CHN_E_INVALID, "chn_index_bin_popcounts: null argument");
+    const chn_index_desc &d = idx->d;
+    HIPCHK(hipSetDevice(d.device));
+    unsigned long long *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_out, d.technical_bins * 8));
+    HIPCHK(hipMemset(d_out, 0, d.technical_bins * 8));
+    hipLaunchKernelGGL(k_bin_popcounts, dim3(4096), dim3(256), 0, 0, idx->words, idx->rows_local, (uint32_t)d.bin_words, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, d.technical_bins * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(CHN_E_HIP, std::string("chn_index_bin_popcounts: ") + hipGetErrorString(e));
+    return CHN_OK;
+}
+
 extern "C" int chn_index_device_words(chn_index *idx, uint64_t **device_words, uint64_t *n_words) {
     if (!idx) return fail(CHN_E_INVALID, "null index");
     if (device_words) *device_words = idx->words;

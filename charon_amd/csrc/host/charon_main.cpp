@@ -263,7 +263,7 @@ public:
     uint64_t ef_size = 0, ef_ones = 0, high_bits = 0;
     uint8_t ef_wl = 0;
     std::vector<uint64_t> low, high;
-    std::vector<uint64_t> bits_per_bin;  // filled by stream_rows: set bits per technical bin (self-check iv)
+    std::vector<uint64_t> bits_per_bin;  // filled by decode_on_device: set bits per technical bin (self-check iv)
 
     explicit IndexFile(const std::string &path) : is_(path, std::ios::binary), path_(path) {
         if (!is_) throw std::runtime_error("cannot open index file " + path);
@@ -314,50 +314,40 @@ public:
         // the two trailing select_support_mcl structures are not needed and not read
     }
 
-    uint64_t low_at(uint64_t i) const {
-        const uint64_t bit = i * ef_wl, wd = bit >> 6, sh = bit & 63;
-        uint64_t v = low[wd] >> sh;
-        if (sh + ef_wl > 64) v |= low[wd + 1] << (64 - sh);
-        return ef_wl == 64 ? v : (v & ((1ULL << ef_wl) - 1));
-    }
-
-    // Decode the Elias-Fano vector into plain interleaved rows, `block_rows` at a time (host RAM never holds the
-    // whole plain index), and hand each block to `sink(row_begin, n_rows, words)`.
-    template <class Sink> void stream_rows(uint64_t block_rows, Sink sink) {
-        const IndexMeta &m = meta;
-        const uint64_t W = m.bin_words, TB = m.technical_bins, S = m.bin_size;
-        std::vector<uint64_t> block(block_rows * W);
-        bits_per_bin.assign(TB, 0);
-        uint64_t row0 = 0, k = 0, hp = 0, prev = 0;
-        bool first = true;
-        const uint64_t tail_mask = (m.bins & 63) ? ~((1ULL << (m.bins & 63)) - 1) : 0ULL;  // technical bins >= B in the last word
-        while (row0 < S) {
-            const uint64_t nrows = std::min(block_rows, S - row0);
-            std::fill(block.begin(), block.begin() + nrows * W, 0ULL);
-            const uint64_t bit_end = (row0 + nrows) * TB;
-            while (k < ef_ones) {
-                // advance to the next one in m_high
-                while (hp < high_bits && !((high[hp >> 6] >> (hp & 63)) & 1)) {
-                    const uint64_t rest = high[hp >> 6] >> (hp & 63);
-                    hp += rest ? (uint64_t)__builtin_ctzll(rest) : 64 - (hp & 63);
-                }
-                if (hp >= high_bits) throw std::runtime_error("sd_vector: m_high holds fewer ones than m_low has elements");
-                const uint64_t pos = ((hp - k) << ef_wl) | (ef_wl ? low_at(k) : 0);
-                if (!first && pos <= prev) throw std::runtime_error("sd_vector: decoded positions are not strictly increasing");
-                if (pos >= ef_size) throw std::runtime_error("sd_vector: decoded position beyond m_size");
-                if (pos >= bit_end) break;
-                const uint64_t wd = pos >> 6;
-                if (tail_mask && (wd % W) == W - 1 && ((1ULL << (pos & 63)) & tail_mask))
-                    throw std::runtime_error("index has a set bit in a technical bin >= num_bins");
-                block[wd - row0 * W] |= 1ULL << (pos & 63);
-                bits_per_bin[(wd % W) * 64 + (pos & 63)] += 1;
-                prev = pos; first = false;
-                ++k; ++hp;
+    // Decode the Elias-Fano vector into the plain interleaved rows ON THE DEVICE (chn_index_decode_ef): m_high goes over in
+    // slices with the matching part of m_low, so neither the host nor the device ever holds a second copy of the plain
+    // index, and the per-one work (rank in m_high, low part, bit set) runs at memory speed instead of ~15 ns per one on a
+    // host core (minutes for an index of the published size).  Self-checks: number of ones in m_high == elements of
+    // m_low; no position beyond m_size or in a technical bin >= num_bins; set bits after decode == ones (a vector whose
+    // positions are not strictly increasing would lose bits); per-bin counts for check (iv).
+    void decode_on_device(chn_index *index, uint64_t slice_words = 1ULL << 24) {
+        const uint64_t n_high = (high_bits + 63) / 64;
+        if (high_bits & 63) high[n_high - 1] &= (1ULL << (high_bits & 63)) - 1;  // bits past the end are not part of the vector
+        uint64_t ones_before = 0;
+        for (uint64_t w0 = 0; w0 < n_high; w0 += slice_words) {
+            const uint64_t nw = std::min(slice_words, n_high - w0);
+            uint64_t ones = 0;
+            for (uint64_t i = 0; i < nw; ++i) ones += (uint64_t)__builtin_popcountll(high[w0 + i]);
+            if (ef_wl && ones_before + ones > ef_ones) throw std::runtime_error("sd_vector: m_high holds more ones than m_low has elements");
+            if (ones) {
+                const uint64_t elem0 = ones_before & ~63ULL;  // 64 elements always end on a word boundary
+                const uint64_t lw0 = elem0 * ef_wl / 64, lw1 = ((ones_before + ones) * ef_wl + 63) / 64;
+                uint64_t bad = 0;
+                if (chn_index_decode_ef(index, ef_size, ef_wl, high.data() + w0, w0 * 64, nw, ones_before, ef_wl ? low.data() + lw0 : nullptr, elem0,
+                                        ef_wl ? lw1 - lw0 : 0, &bad) != CHN_OK)
+                    throw std::runtime_error(std::string("device decode of the index failed: ") + chn_last_error());
+                if (bad) throw std::runtime_error("index has " + std::to_string(bad) + " set bits beyond m_size or in a technical bin >= num_bins");
             }
-            sink(row0, nrows, block.data());
-            row0 += nrows;
+            ones_before += ones;
         }
-        if (k != ef_ones) throw std::runtime_error("sd_vector: not all ones were consumed");
+        if (!ef_wl) ef_ones = ones_before;  // no low parts: the count is only in m_high
+        if (ones_before != ef_ones) throw std::runtime_error("sd_vector: m_high holds fewer ones than m_low has elements");
+        bits_per_bin.assign(meta.technical_bins, 0);
+        if (chn_index_bin_popcounts(index, bits_per_bin.data()) != CHN_OK) throw std::runtime_error(std::string("bin popcounts failed: ") + chn_last_error());
+        uint64_t total = 0;
+        for (uint64_t c : bits_per_bin) total += c;
+        if (total != ef_ones) throw std::runtime_error("sd_vector: decoded positions are not strictly increasing (" + std::to_string(total) + " distinct bits for " +
+                                                       std::to_string(ef_ones) + " ones)");
     }
 };
 
@@ -1065,8 +1055,7 @@ int dehost_main(DehostArguments &opt) {
     for (uint64_t b = 0; b < meta.bins; ++b) d.bin_to_category[b] = meta.category_index(meta.bin_to_category.at((uint8_t)b));
     chn_index *index = nullptr;
     CHN_CHECK(chn_index_create(&d, &index));
-    const uint64_t block_rows = std::max<uint64_t>(1, (256ULL << 20) / (8 * meta.bin_words));
-    file.stream_rows(block_rows, [&](uint64_t row0, uint64_t nrows, const uint64_t *words) { CHN_CHECK(chn_index_upload_rows(index, row0, nrows, words)); });
+    file.decode_on_device(index);
     file.low.clear(); file.low.shrink_to_fit(); file.high.clear(); file.high.shrink_to_fit();
     g_log.info("Index loaded");
     // loader self-check (iv), SURVEY 8(c): a bin that received n distinct values through h hash functions should have

@@ -67,6 +67,17 @@ int chn_index_create(const chn_index_desc *desc, chn_index **out);
  * Replaces the archive(ibf_) step of Index::serialize (include/index.hpp:130) after EF decoding; the
  * loader streams row blocks so host RAM never holds the whole plain index. */
 int chn_index_upload_rows(chn_index *idx, uint64_t row_begin, uint64_t n_rows, const uint64_t *host_words);
+/* Elias-Fano (sdsl::sd_vector) decode ON THE DEVICE: the alternative to chn_index_upload_rows for the loader, replacing the
+ * archive(ibf_) step of Index::serialize (include/index.hpp:130) for the compressed IBF the file really holds.
+ * `high` is a slice of m_high starting at bit `high_bit0` (a multiple of 64) with `n_high_words` words; `ones_before` = number of
+ * set bits of m_high before that slice (the caller keeps the running popcount); `low` holds the packed m_low elements starting
+ * with element `low_elem0` <= ones_before, `n_low_words` words (the last partial word included).  Every one of the slice is turned
+ * into its plain bit position ((zeros before it) << wl | low part) and set in the index words; positions outside this shard's
+ * rows are skipped.  *bad_bits counts positions >= m_size or in technical bins >= bins (must stay 0 for a well-formed file). */
+int chn_index_decode_ef(chn_index *idx, uint64_t m_size, uint32_t wl, const uint64_t *high, uint64_t high_bit0, uint64_t n_high_words,
+                        uint64_t ones_before, const uint64_t *low, uint64_t low_elem0, uint64_t n_low_words, uint64_t *bad_bits);
+/* set bits per technical bin over the rows this object holds (loader self-check iv); out[technical_bins] */
+int chn_index_bin_popcounts(chn_index *idx, uint64_t *out);
 /* Device pointer to the shard's words (for on-device index fabrication and for download in tests). */
 int chn_index_device_words(chn_index *idx, uint64_t **device_words, uint64_t *n_words);
 int chn_index_download_rows(chn_index *idx, uint64_t row_begin, uint64_t n_rows, uint64_t *host_words);

@@ -431,3 +431,44 @@ def test_hash_function_counts_and_long_windows(api, oracle_lib):
         reads = util.sample_reads(r, gs, 130, (1, 3000), sub_rate=0.02) + [b"A" * 700, b"ACGT" * 200, gs[0][:w], gs[0][:w - 1], gs[1][:k]]
         check(api, oracle_lib, oidx, reads)
         oidx.free()
+
+
+@pytest.mark.parametrize("bins,bin_size,ones,slice_words", [(100, 5000, 60000, 64), (8, 70001, 300000, 1000), (130, 997, 1, 1 << 20),
+                                                            (3, 4096, 200000, 7)])
+def test_device_elias_fano_decode(api, bins, bin_size, ones, slice_words):
+    """chn_index_decode_ef (loader): sd_vector low/high arrays -> plain rows on the device, sliced; checked against the positions
+    the vector was encoded from (oracle/pyref.ef_encode, the restatement of sdsl's sd_vector layout)."""
+    from oracle import pyref
+    rng = np.random.default_rng(bins * 7 + ones)
+    tb = (bins + 63) // 64 * 64
+    universe = tb * bin_size
+    # positions only in real bins (bin < bins), strictly increasing
+    rows = rng.integers(0, bin_size, ones * 2)
+    cols = rng.integers(0, bins, ones * 2)
+    pos = np.unique(rows.astype(np.int64) * tb + cols)[:ones]
+    wl, lowbits, low, highbits, high = pyref.ef_encode([int(p) for p in pos], universe)
+    to_words = lambda v, bits: np.frombuffer(v.to_bytes(((bits + 63) // 64) * 8, "little"), np.uint64).copy()
+    g = api.Index(api.make_desc(bins, bin_size, [0] * bins, 1, 0))
+    try:
+        bad = g.decode_ef(universe, wl, to_words(high, highbits), highbits, to_words(low, lowbits) if wl else np.zeros(0, np.uint64),
+                          slice_words=slice_words)
+        assert bad == 0
+        got = g.download()
+        want = np.zeros(universe // 64, np.uint64)
+        np.bitwise_or.at(want, pos >> 6, np.uint64(1) << (pos & 63).astype(np.uint64))
+        assert np.array_equal(got, want)
+        pc = g.bin_popcounts()
+        assert np.array_equal(pc, np.bincount(pos % tb, minlength=tb).astype(np.uint64))
+    finally:
+        g.destroy()
+    # a bit in a technical-only bin (>= bins) or beyond m_size is reported, not set
+    if bins % 64:
+        bad_pos = [int(pos[0] // tb * tb + bins)] if int(pos[0] // tb * tb + bins) not in set(pos.tolist()) else []
+        if bad_pos:
+            wl, lowbits, low, highbits, high = pyref.ef_encode(bad_pos, universe)
+            g = api.Index(api.make_desc(bins, bin_size, [0] * bins, 1, 0))
+            try:
+                assert g.decode_ef(universe, wl, to_words(high, highbits), highbits, to_words(low, lowbits) if wl else np.zeros(0, np.uint64)) == 1
+                assert not g.download().any()
+            finally:
+                g.destroy()
