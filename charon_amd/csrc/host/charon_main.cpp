@@ -231,6 +231,7 @@ struct IndexMeta {
 class IndexFile {
     std::ifstream is_;
     std::string path_;
+    long long file_size_ = 0;
     template <class T> T pod() {
         T v;
         is_.read(reinterpret_cast<char *>(&v), sizeof(T));
@@ -242,6 +243,7 @@ class IndexFile {
         if (n > (1u << 20)) throw std::runtime_error("implausible string length in index file near offset " + std::to_string((long long)is_.tellg()));
         std::string s((size_t)n, '\0');
         if (n) is_.read(&s[0], (std::streamsize)n);
+        if (!is_) throw std::runtime_error("index file truncated inside a string");
         return s;
     }
     void int_vector(uint8_t &width, uint64_t &bits, std::vector<uint64_t> &words) {
@@ -250,9 +252,11 @@ class IndexFile {
         const float growth = pod<float>();
         const uint64_t n_words = pod<uint64_t>();
         bits = pod<uint64_t>();
-        if (width < 1 || width > 64 || growth != 1.5f || n_words * 64 < bits)
+        if (width < 1 || width > 64 || growth != 1.5f || n_words > (~0ULL >> 6) || n_words * 64 < bits)
             throw std::runtime_error("sdsl int_vector framing check failed at file offset " + std::to_string(at) +
                                      " (width/growth_factor/word count/bit size do not agree)");
+        const long long here = (long long)is_.tellg();
+        if (here < 0 || n_words > (uint64_t)(file_size_ - here) / 8) throw std::runtime_error("index file truncated inside an int_vector");
         words.assign(n_words + 1, 0);
         is_.read(reinterpret_cast<char *>(words.data()), (std::streamsize)(n_words * 8));
         if (!is_) throw std::runtime_error("index file truncated inside an int_vector");
@@ -267,6 +271,9 @@ public:
 
     explicit IndexFile(const std::string &path) : is_(path, std::ios::binary), path_(path) {
         if (!is_) throw std::runtime_error("cannot open index file " + path);
+        is_.seekg(0, std::ios::end);
+        file_size_ = (long long)is_.tellg();
+        is_.seekg(0, std::ios::beg);
         IndexMeta &m = meta;
         m.window_size = pod<uint8_t>();
         m.kmer_size = pod<uint8_t>();
@@ -1592,7 +1599,7 @@ int main(int argc, char **argv) {
             while (in.next(blk, max_recs, max_bytes))
                 for (const RecView &r : blk.recs) {
                     unsigned long long h = 1469598103934665603ULL; long qs = 0;
-                    for (uint32_t i = 0; i < r.seq_len; ++i) { h ^= (unsigned char)"ACGTN"[g_codes.t[(unsigned char)r.seq[i]] & 7]; h *= 1099511628211ULL; }
+                    for (uint32_t i = 0; i < r.seq_len; ++i) { h ^= (unsigned char)"ACGTN??"[std::min<unsigned>(g_codes.t[(unsigned char)r.seq[i]], 5)]; h *= 1099511628211ULL; }
                     for (uint32_t i = 0; i < r.qual_len; ++i) qs += r.qual[i] - 33;
                     std::cout << std::string(r.id, r.id_len) << "\t" << r.seq_len << "\t" << r.qual_len << "\t" << qs << "\t" << h << "\n";
                 }

@@ -269,3 +269,25 @@ def test_cli_errors(tmp_path):
     rc, out, err = run_cli(["--db", os.path.join(G, "cfg1.idx"), "--dist", "weibull", fq], str(tmp_path))
     assert rc == 0 and out == ""
     assert "Supported distributions" in open(tmp_path / "charon.log").read()
+
+
+def test_cli_rejects_corrupted_index_payload(tmp_path):
+    """the sd_vector payload is decoded on the device (chn_index_decode_ef); a damaged m_high / m_low must be reported by the
+    loader's self-checks (ones in m_high vs elements of m_low, bits beyond m_size or in technical bins >= num_bins, distinct bits
+    after decode), never classified with"""
+    fq = os.path.join(G, "cfg1_reads.fastq.gz")
+    src = open(os.path.join(G, "cfg1.idx"), "rb").read()
+    n = len(src)
+    outcomes = []
+    for where, mask in ((n - 9, 0xFF), (n - 2000, 0x10), (n // 2, 0x01), (n // 2 + 777, 0x80)):
+        b = bytearray(src)
+        b[where] ^= mask
+        p = tmp_path / "bad.idx"
+        p.write_bytes(bytes(b))
+        rc, out, err = run_cli(["--db", str(p), fq], str(tmp_path))
+        outcomes.append((rc, err.strip().split("\n")[-1] if err.strip() else ""))
+    # every flip changes the decoded bit set; the damage is either caught by a structural check (rc != 0) or - when the flip moved
+    # one bit to another legal position - by the reference-file self-check warning in the log
+    assert any(rc != 0 for rc, _ in outcomes), outcomes
+    for rc, msg in outcomes:
+        assert rc != 0 or "self-check" in open(tmp_path / "charon.log").read(), outcomes

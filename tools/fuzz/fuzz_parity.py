@@ -1,0 +1,97 @@
+"""Time-boxed randomised parity soak: GPU path (through the C ABI) vs the CPU oracle on random index shapes and reads.
+    python tools/fuzz/fuzz_parity.py <seconds> <seed>     (needs a GPU; prints one line per trial, exits 1 on the first mismatch)
+Wider than tests/test_gpu_parity.py::test_randomised_parameter_sweep: hash function counts 1..5, up to 255 bins, reads up to 30 kb,
+thousands of reads per batch, batch capacities close to the input size."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from tests import util  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+import charon_amd.api as api  # noqa: E402
+from charon_amd import pack  # noqa: E402
+
+
+def trial(r, t):
+    k = int(r.integers(3, 28))
+    w = int(k + r.integers(0, 40))
+    B = int(r.choice([2, 3, 5, 8, 9, 33, 64, 65, 100, 129, 200, 255]))
+    C = int(min(B, r.integers(2, 9)))
+    h = int(r.integers(1, 6))
+    b2c = [int(x) for x in r.integers(0, C, B)]
+    for c in range(C):
+        b2c[c % B] = c
+    cats = ["human"] + ["c%d" % i for i in range(1, C)]
+    glen = int(r.integers(300, 20000))
+    gs = [util.random_seq(r, glen) for _ in range(B)]
+    mins = []
+    for g in gs:
+        mins.append(np.unique(po.minimisers(g.decode(), k, w)).astype(np.uint64))
+    bin_size = int(r.integers(500, 400000))
+    oidx = po.Index.new(B, bin_size, b2c, cats, k=k, w=w, nhash=h)
+    for b, m in enumerate(mins):
+        if len(m):
+            oidx.emplace_many(m, b)
+    n = int(r.choice([1, 7, 64, 65, 500, 3000]))
+    lmax = int(r.choice([30, 150, 1000, 5000, 30000]))
+    if n * lmax > 6_000_000:
+        n = max(1, 6_000_000 // lmax)
+    paired = bool(r.integers(0, 2)) or C > 2
+    reads = util.sample_reads(r, gs, n, (0, lmax), sub_rate=float(r.choice([0.0, 0.02, 0.1])), random_fraction=0.2)
+    mates = util.sample_reads(r, gs, n, (0, min(lmax, 2000)), sub_rate=0.03) if paired else None
+
+    def spice(s):
+        a = bytearray(s)
+        if len(a) > 10 and r.random() < 0.2:
+            for p in r.integers(0, len(a), int(r.integers(1, 8))):
+                a[int(p)] = ord("N")
+        if len(a) > 200 and r.random() < 0.1:
+            p = int(r.integers(0, len(a) - 150))
+            a[p:p + 150] = (b"AC" * 75) if r.random() < 0.5 else b"T" * 150
+        return bytes(a)
+    reads = [spice(s) for s in reads]
+    if mates:
+        mates = [spice(s) for s in mates]
+    if not any(len(s) for s in reads):
+        reads[0] = b"ACGT" * 20
+    g = util.gpu_index_from_oracle(api, oidx)
+    try:
+        p = pack.pack_reads(reads, mates)
+        st = api.Stream(g, max(n, 1), p["n_bases"])
+        st.set_model(api.default_model(C, oidx.host_index if not paired else 0, paired=paired))
+        st.submit_host(p, np.full(n, 40.0, np.float32), np.zeros(n, np.float32))
+        gpu = st.wait_host()
+        st.destroy()
+        seqs, offs, split = util.concat(reads, mates)
+        orc = oidx.process_reads(seqs, offs, mate_split=split, mq_const=40.0, threads=8)
+        util.assert_parity(gpu, orc)
+    finally:
+        g.destroy()
+        oidx.free()
+    return "k=%d w=%d B=%d C=%d h=%d S=%d n=%d lmax=%d paired=%d hashes=%d" % (k, w, B, C, h, bin_size, n, lmax, paired, int(gpu["num_hashes"].sum()))
+
+
+def main():
+    secs, seed = float(sys.argv[1]), int(sys.argv[2])
+    po.build()
+    r = np.random.default_rng(seed)
+    t0, t = time.time(), 0
+    while time.time() - t0 < secs:
+        state = r.bit_generator.state
+        try:
+            msg = trial(r, t)
+        except Exception as e:  # noqa: BLE001
+            print("MISMATCH/ERROR in trial %d (seed %d): %r" % (t, seed, e), flush=True)
+            print("rng state:", state, flush=True)
+            raise
+        print("trial %d ok  %s  [%.0fs]" % (t, msg, time.time() - t0), flush=True)
+        t += 1
+    print("fuzz_parity: %d trials, no mismatch" % t)
+
+
+if __name__ == "__main__":
+    main()
