@@ -261,7 +261,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_minimise_probe", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_avg,
-                         "other_kernels_avg_ms": {"k_count_rows": k2_ms / max(k2_n, 1), "k_model_call": k3_ms / max(k3_n, 1),
+                         "other_kernels_avg_ms": {"k_count_wavelog": k2_ms / max(k2_n, 1), "k_model_call": k3_ms / max(k3_n, 1),
                                                   "whole_chain": chain_ms / max(chain_n, 1)}},
         }
         if world == 1 and not args.no_cpu_baseline and not rows_mode and not paired:

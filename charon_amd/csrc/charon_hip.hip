@@ -729,57 +729,99 @@ struct K3Args {
     uint32_t min_hits, paired, host_index;
 };
 
-__device__ __forceinline__ float kde_prob_dev(const float *data, uint32_t n, float h, float x) {
-    // KDEParams::prob / K (include/classify_stats.hpp:242-252): K evaluated in double, accumulated in float.
-    // A term with |t| > 15 is exp(-112.5)/sqrt(2 pi) < 6e-50, which rounds to +0.0f, and adding +0.0f leaves the float
-    // accumulator unchanged -- skipping it is exact (it removes most of the h = 0.001 terms).  NaN compares false.
+__device__ __forceinline__ uint32_t rl_u32(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+__device__ __forceinline__ float rl_f32(float v, uint32_t lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)lane)); }
+
+// KDEParams::prob / K (include/classify_stats.hpp:242-252): K evaluated in double, accumulated in float IN DATA ORDER.
+// Evaluated by the whole wavefront for one wave-uniform x: lane j computes the term of point base + j (the expensive double
+// exp), then the terms are added to the (uniform) float accumulator in ascending point order through readlane, so the sum
+// is bit-identical to the reference's sequential loop while the exps run 64 wide.
+// A term with |t| > 15 is exp(-112.5)/sqrt(2 pi) < 6e-50, which rounds to +0.0f, and adding +0.0f leaves the float
+// accumulator unchanged -- skipping it is exact (it removes most of the narrow-bandwidth terms).  NaN compares false.
+__device__ __forceinline__ float kde_prob_wave(const float *data, uint32_t n, float h, float x) {
+    const uint32_t lane = __lane_id();
     float total = 0.0f;
-    for (uint32_t i = 0; i < n; ++i) {
-        const float t = (x - data[i]) / h;
-        if (fabsf(t) > 15.0f) continue;
-        const double kd = exp(-((double)t * (double)t) / 2.0) / sqrt(2 * 3.141592653589793238463);
-        total += (float)kd;
+    for (uint32_t base = 0; base < n; base += WAVE) {
+        const uint32_t i = base + lane;
+        float term = 0.0f;
+        bool live = false;
+        if (i < n) {
+            const float t = (x - data[i]) / h;
+            if (!(fabsf(t) > 15.0f)) {
+                const double kd = exp(-((double)t * (double)t) / 2.0) / sqrt(2 * 3.141592653589793238463);
+                term = (float)kd;
+                live = true;
+            }
+        }
+        uint64_t m = __ballot(live);
+        while (m) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            total += rl_f32(term, j);
+        }
     }
     return total / (h * (float)n);
 }
 
-// Model::prob (include/classify_stats.hpp:370-389) of category c for a read with `uq` unique hits out of `nh` minimisers
-__device__ __forceinline__ double model_prob_compute(const K3Args &a, uint32_t c, uint32_t uq, uint32_t nh) {
+// Model::prob (include/classify_stats.hpp:370-389) of category c for a read with `uq` unique hits out of `nh` minimisers;
+// c, uq, nh wave-uniform, every lane returns the same value
+__device__ __forceinline__ double model_prob_wave(const K3Args &a, uint32_t c, uint32_t uq, uint32_t nh) {
     const float x = (float)uq / (float)nh;  // unique proportion (include/read_entry.hpp:140-150)
     float p_err;
     if (x != x) p_err = x;
     else if (x < 0.0f) p_err = 0.0f;
     else p_err = (float)exp((double)(a.log_rate - a.rate * x));  // stats::dexp(x, 300) = exp(log(300) - 300 x)
-    float p_pos = kde_prob_dev(a.data + a.tab[c], a.tab[a.C + c], a.h_pos, x);
-    const float p_neg = kde_prob_dev(a.data + a.tab[2 * a.C + c], a.tab[3 * a.C + c], a.h_neg, x);
+    float p_pos = kde_prob_wave(a.data + a.tab[c], a.tab[a.C + c], a.h_pos, x);
+    const float p_neg = kde_prob_wave(a.data + a.tab[2 * a.C + c], a.tab[3 * a.C + c], a.h_neg, x);
     if (x == 1.0f) p_pos = 1.0f;
     const float total = p_err + p_pos + p_neg;
     return (double)(p_pos / total);  // probabilities_ starts at 1 and is multiplied once (:56,277)
 }
+
 // The probability is a pure function of (c, uq, nh) for a fixed model, and a batch holds few distinct triples (reads of
 // similar length), so it is memoised in a persistent direct-mapped table.  An entry is {check, prob} with
 // check = ~(key ^ bits(prob)): a torn, stale or empty (all-zero) entry fails the check and is simply recomputed, so no
-// ordering between writers and readers is needed; racing writers store identical values.
-__device__ __forceinline__ double model_prob_dev(const K3Args &a, uint32_t c, uint32_t uq, uint32_t nh) {
-    if (!a.memo || nh >= (1u << 28) || uq >= (1u << 28)) return model_prob_compute(a, c, uq, nh);
+// ordering between writers and readers is needed; racing writers store identical values.  Misses are resolved by the
+// whole wavefront, one distinct (uq, nh) at a time (lanes that miss on the same pair share the evaluation).
+__device__ __forceinline__ double model_prob_lookup(const K3Args &a, bool valid, uint32_t c, uint32_t uq, uint32_t nh) {
+    const bool keyed = a.memo && nh < (1u << 28) && uq < (1u << 28);
     const uint64_t key = ((uint64_t)c << 56) | ((uint64_t)nh << 28) | uq;
     ulonglong2 *slot = a.memo + (mix64(key) & a.memo_mask);
-    const ulonglong2 e = *slot;
-    if (e.x == ~(key ^ e.y)) return __longlong_as_double((long long)e.y);
-    const double p = model_prob_compute(a, c, uq, nh);
-    const uint64_t bits = (uint64_t)__double_as_longlong(p);
-    *slot = make_ulonglong2(~(key ^ bits), bits);
+    double p = 0.0;
+    bool have = !valid;
+    if (valid && keyed) {
+        const ulonglong2 e = *slot;
+        if (e.x == ~(key ^ e.y)) { p = __longlong_as_double((long long)e.y); have = true; }
+    }
+    uint64_t miss = __ballot(!have);
+    const uint32_t lane = __lane_id();
+    while (miss) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(miss);
+        const uint32_t kuq = rl_u32(uq, l), knh = rl_u32(nh, l);
+        const double v = model_prob_wave(a, c, kuq, knh);
+        if (!have && uq == kuq && nh == knh) { p = v; have = true; }
+        if (lane == l && keyed) {
+            const uint64_t bits = (uint64_t)__double_as_longlong(v);
+            *slot = make_ulonglong2(~(key ^ bits), bits);
+        }
+        miss = __ballot(!have);
+    }
     return p;
 }
 
 __global__ __launch_bounds__(256) void k_model_call(const K3Args a) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n_reads) return;
+    const uint32_t r0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = r0 < a.n_reads;
+    const uint32_t r = valid ? r0 : 0u;  // lanes past the end stay in the wave-wide miss handling, with nothing to ask
     const uint32_t C = a.C;
     const uint32_t nh = a.num_hashes[r];
     const uint32_t *cnts = a.counts + (size_t)r * C, *uq = a.unique + (size_t)r * C;
     double *prob = a.prob + (size_t)r * C;
-    for (uint32_t c = 0; c < C; ++c) prob[c] = model_prob_dev(a, c, uq[c], nh);
+    for (uint32_t c = 0; c < C; ++c) {
+        const double p = model_prob_lookup(a, valid, c, uq[c], nh);
+        if (valid) prob[c] = p;
+    }
+    if (!valid) return;
     const float mq = a.mean_quality ? a.mean_quality[r] : 0.0f;
     const float comp = a.compression ? a.compression[r] : 0.0f;
     const uint32_t length = a.len1[r] + (a.len2 ? a.len2[r] : 0u);
