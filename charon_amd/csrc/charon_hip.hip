@@ -506,6 +506,7 @@ struct K2Args {
 };
 
 #define K2_THREADS 512
+#define K2_UNROLL 4
 template <int W>
 __global__ __launch_bounds__(K2_THREADS) void k_count_wavelog(const K2Args a) {
     extern __shared__ __align__(16) unsigned char smem2[];
@@ -526,10 +527,11 @@ __global__ __launch_bounds__(K2_THREADS) void k_count_wavelog(const K2Args a) {
     const uint64_t *rows = a.rows + base * W;
     const uint32_t *log = a.rowlog + base;
     const uint64_t lastmask = (B & 63u) ? ((1ULL << (B & 63u)) - 1) : ~0ULL;
-    // pass A: per-bin totals of each of the 64 reads.  Four compact entries per load: the loop is latency-bound per thread.
+    // pass A: per-bin totals of each of the 64 reads.  Four compact entries per load and K2_UNROLL loads in flight per thread:
+    // the loop is latency-bound per thread, not bandwidth-bound.
     const uint4 *log4 = reinterpret_cast<const uint4 *>(log);
-    for (uint32_t i4 = tid; i4 * 4 < count; i4 += K2_THREADS) {
-        const uint4 v4 = log4[i4];
+    const uint32_t count4 = (count + 3) / 4;
+    auto pass_a = [&](const uint4 v4, uint32_t i4) {
         const uint32_t xs[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -553,29 +555,35 @@ __global__ __launch_bounds__(K2_THREADS) void k_count_wavelog(const K2Args a) {
                 }
             }
         }
+    };
+    for (uint32_t i4 = tid; i4 < count4; i4 += K2_THREADS * K2_UNROLL) {
+        uint4 v[K2_UNROLL];
+#pragma unroll
+        for (int u = 0; u < K2_UNROLL; ++u) {
+            const uint32_t j = i4 + u * K2_THREADS;
+            v[u] = j < count4 ? log4[j] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < K2_UNROLL; ++u) pass_a(v[u], i4 + u * K2_THREADS);
     }
     __syncthreads();
-    // first bin with the strictly largest total per category (:102-115), one thread per read
-    if (tid < WAVE) {
-        const uint32_t o = tid;
+    // first bin with the strictly largest total per category (:102-115): one thread per (read, category), bins scanned in
+    // ascending order with the running best in registers
+    for (uint32_t i = tid; i < WAVE * C; i += K2_THREADS) {
+        const uint32_t o = i / C, c = i % C;
+        uint32_t best = 255, bestv = 0;
         for (uint32_t b = 0; b < B; ++b) {
-            const uint32_t c = s_b2c[b];
-            const uint32_t cur = chosen[o * C + c];
-            if (cur == 255 || tot[o * B + b] > tot[o * B + cur]) chosen[o * C + c] = (uint8_t)b;
+            const uint32_t t = tot[o * B + b];
+            if (s_b2c[b] == c && (best == 255 || t > bestv)) { best = b; bestv = t; }
         }
+        chosen[i] = (uint8_t)best;
+        if (best != 255) atomicOr((unsigned long long *)&cmask[o * W + (best >> 6)], 1ULL << (best & 63u));
         const uint32_t gi = g * WAVE + o;
-        const bool valid = gi < a.n_reads;
-        const uint32_t r = valid ? a.order[gi] : 0;
-        for (uint32_t c = 0; c < C; ++c) {
-            const uint32_t cb = chosen[o * C + c];
-            if (cb != 255) cmask[o * W + (cb >> 6)] |= 1ULL << (cb & 63u);
-            if (valid) a.counts[(size_t)r * C + c] = cb == 255 ? 0u : tot[o * B + cb];  // a category without bins keeps 0
-        }
+        if (gi < a.n_reads) a.counts[(size_t)a.order[gi] * C + c] = best == 255 ? 0u : bestv;  // a category without bins keeps 0
     }
     __syncthreads();
     // pass B: a minimiser is a unique hit if exactly one category's chosen bin contains it (:121-136)
-    for (uint32_t i4 = tid; i4 * 4 < count; i4 += K2_THREADS) {
-        const uint4 v4 = log4[i4];
+    auto pass_b = [&](const uint4 v4, uint32_t i4) {
         const uint32_t xs[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -598,6 +606,16 @@ __global__ __launch_bounds__(K2_THREADS) void k_count_wavelog(const K2Args a) {
             }
             if (found == 1) atomicAdd(&unq[o * C + s_b2c[fbin]], 1u);
         }
+    };
+    for (uint32_t i4 = tid; i4 < count4; i4 += K2_THREADS * K2_UNROLL) {
+        uint4 v[K2_UNROLL];
+#pragma unroll
+        for (int u = 0; u < K2_UNROLL; ++u) {
+            const uint32_t j = i4 + u * K2_THREADS;
+            v[u] = j < count4 ? log4[j] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < K2_UNROLL; ++u) pass_b(v[u], i4 + u * K2_THREADS);
     }
     __syncthreads();
     for (uint32_t i = tid; i < WAVE * C; i += K2_THREADS) {
