@@ -261,6 +261,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_minimise_probe", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_avg,
+                         "gathers_per_s": (total_min * index.desc.hash_funs / (k1_avg * 1e-3)) if k1_avg > 0 else 0.0,
+                         "note": "HBM-bound on random row probes: each probe uses 8*W bytes of a 128-byte line, so traffic/algorithmic ~ 8x is "
+                                 "line granularity, not re-reads; the measured pure-gather roof of this chip is 48.6e9 (default policy) to "
+                                 "54.3e9 (nt) gathers/s from a 39 GB table (profiles/r01/gather_microbench.txt, gather_policy_microbench.txt)",
                          "other_kernels_avg_ms": {"k_count_wavelog": k2_ms / max(k2_n, 1), "k_model_call": k3_ms / max(k3_n, 1),
                                                   "whole_chain": chain_ms / max(chain_n, 1)}},
         }
