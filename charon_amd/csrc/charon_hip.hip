@@ -129,6 +129,7 @@ struct K1Args {
     uint32_t *rowlog;        // MODE_ROWS: compact entry (see encode_row) of every log entry; MODE_LIST: owner lane
     const uint64_t *wave_base;
     uint32_t *wave_count;    // MODE_ROWS: entries written by wavefront g
+    uint32_t nt_probes;      // non-temporal row gathers (index much larger than the Infinity Cache)
     const uint8_t *read_bin; // MODE_EMPLACE: target bin of "read" (genome chunk) r
     uint32_t ablate;         // diagnostics only (CHN_ABLATE env): 1 = skip the gathers, 2 = skip hash+gathers
 };
@@ -314,17 +315,15 @@ __global__ __launch_bounds__(WAVE) void k_minimise_probe(const K1Args a) {
                     if (i < a.h) {
                         if (a.ablate & 3u) { P.w[i][0] = rows_[i]; for (int w = 1; w < W; ++w) P.w[i][w] = val; continue; }
                         const uint64_t *p = a.words + (rows_[i] - a.row_begin) * W;
-                        // non-temporal: a probed line is never reused, keep it from displacing the row/base lines in L2
-                        if (W == 1) {
-                            P.w[i][0] = __builtin_nontemporal_load(p);
-                        } else if (W == 2) {
-                            P.w[i][0] = __builtin_nontemporal_load(p); P.w[i][W > 1 ? 1 : 0] = __builtin_nontemporal_load(p + 1);
-                        } else if (W == 3) {
-                            P.w[i][0] = __builtin_nontemporal_load(p); P.w[i][W > 1 ? 1 : 0] = __builtin_nontemporal_load(p + 1);
-                            P.w[i][W > 2 ? 2 : 0] = __builtin_nontemporal_load(p + 2);
+                        // Cache policy by index size (tools/gather_policy_bench.hip): from a table far larger than the 256 MiB Infinity
+                        // Cache a probed line is never reused and `nt` gathers sustain 11 % more (54.3 vs 48.8 G/s at 39 GB); from a
+                        // ~1 GiB table a quarter of the probes hit the Infinity Cache and the default policy wins (53.2 vs 49.8 G/s).
+                        if (a.nt_probes) {
+#pragma unroll
+                            for (int w = 0; w < W; ++w) P.w[i][w] = __builtin_nontemporal_load(p + w);
                         } else {
-                            P.w[i][0] = __builtin_nontemporal_load(p); P.w[i][W > 1 ? 1 : 0] = __builtin_nontemporal_load(p + 1);
-                            P.w[i][W > 2 ? 2 : 0] = __builtin_nontemporal_load(p + 2); P.w[i][W > 3 ? 3 : 0] = __builtin_nontemporal_load(p + 3);
+#pragma unroll
+                            for (int w = 0; w < W; ++w) P.w[i][w] = p[w];
                         }
                     }
             }
@@ -1664,6 +1663,8 @@ static int submit_impl(chn_stream *s, const chn_batch *b, bool list_mode) {
     a.bases = bases; a.nmask = nmask; a.off1 = off1; a.off2 = off2; a.len1 = sl.len1; a.len2 = sl.len2;
     a.order = s->d_order.as<uint32_t>();
     if (const char *ab = std::getenv("CHN_ABLATE")) a.ablate = (uint32_t)std::atoi(ab);
+    a.nt_probes = s->idx->rows_local * d.bin_words * 8 > (4ULL << 30) ? 1u : 0u;
+    if (const char *nt = std::getenv("CHN_NT_PROBES")) a.nt_probes = (uint32_t)std::atoi(nt);  // A/B diagnostic
     a.num_hashes = sl.d_num_hashes.as<uint32_t>(); a.counts = sl.d_counts.as<uint32_t>(); a.unique = sl.d_unique.as<uint32_t>();
     a.rows = list_mode ? s->d_list.as<uint64_t>() : s->d_rows.as<uint64_t>(); a.rowlog = s->d_rowown.as<uint32_t>();
     a.wave_base = s->d_wbase.as<uint64_t>(); a.wave_count = s->d_wcount.as<uint32_t>();
