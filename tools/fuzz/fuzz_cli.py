@@ -1,0 +1,136 @@
+"""Time-boxed randomised soak of the drop-in boundary: `charon dehost` (GPU) vs the oracle's dehost on random indexes and read files.
+    python tools/fuzz/fuzz_cli.py <seconds> <seed>     (needs a GPU)
+Varies: bins / categories / k / w, FASTQ vs FASTA, gz, wrapped lines, CRLF, lower case + IUPAC, zero-length reads, single vs paired,
+batch size (CHARON_BATCH_READS), -t, --extract with a small --num_reads_to_fit (training path), thresholds."""
+import gzip
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from tests import util  # noqa: E402
+from tests.test_gpu_cli import assert_same_tsv  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+
+EXE = os.path.join(ROOT, "charon_amd", "bin", "charon")
+
+
+def write_reads(path, names, seqs, r, fastq, gz, wrapw, crlf):
+    eol = "\r\n" if crlf else "\n"
+    wrap = (lambda s: eol.join(s[i:i + wrapw] for i in range(0, len(s), wrapw)) if s else "") if wrapw else (lambda s: s)
+    out = []
+    for nm, s in zip(names, seqs):
+        s = s.decode()
+        if fastq:
+            q = "".join(chr(33 + int(x)) for x in r.integers(2, 41, len(s)))
+            out.append("@" + nm + eol + wrap(s) + eol + "+" + eol + wrap(q) + eol)
+        else:
+            out.append(">" + nm + eol + wrap(s) + eol)
+    data = "".join(out).encode()
+    if gz:
+        with gzip.open(path, "wb") as f:
+            f.write(data)
+    else:
+        with open(path, "wb") as f:
+            f.write(data)
+
+
+def trial(r, d):
+    k = int(r.integers(5, 28))
+    w = int(k + r.integers(0, 30))
+    nfiles = int(r.choice([2, 3, 5, 9]))
+    cats = ["human", "bacteria", "virus"][:int(min(nfiles, r.integers(2, 4)))]
+    paired = bool(r.integers(0, 2)) or len(cats) > 2
+    gs = [util.random_seq(r, int(r.integers(2000, 9000))) for _ in range(nfiles)]
+    files = []
+    for i, g in enumerate(gs):
+        p = os.path.join(d, "g%d.fa" % i)
+        with open(p, "w") as f:
+            f.write(">g%d\n%s\n" % (i, g.decode()))
+        files.append((p, cats[i % len(cats)]))
+    oidx = po.Index.from_fasta(files, sorted(cats), k=k, w=w)
+    oidx.store(os.path.join(d, "x.idx"))
+    n = int(r.choice([1, 2, 30, 200, 700]))
+    lmax = int(r.choice([60, 300, 2000]))
+    fastq = bool(r.random() < 0.8)
+    gz = bool(r.random() < 0.3)
+    wrapw = int(r.choice([0, 0, 61]))
+    crlf = bool(r.random() < 0.15)
+    ext = (".fastq" if fastq else ".fasta") + (".gz" if gz else "")
+
+    def spice(s):
+        a = bytearray(s)
+        if len(a) > 30 and r.random() < 0.2:
+            a[3:9] = b"nryKMs"
+        if len(a) > 30 and r.random() < 0.1:
+            a = bytearray(bytes(a).lower())
+        if r.random() < 0.03:
+            a = bytearray()
+        return bytes(a)
+    m1 = [spice(s) for s in util.sample_reads(r, gs, n, (20, lmax), sub_rate=0.03, random_fraction=0.15)]
+    f1 = os.path.join(d, "r_1" + ext)
+    args, kw = [], {}
+    if paired:
+        m2 = [spice(s) for s in util.sample_reads(r, gs, n, (20, lmax), sub_rate=0.03)]
+        f2 = os.path.join(d, "r_2" + ext)
+        write_reads(f1, ["q%d extra/1" % i for i in range(n)], m1, r, fastq, gz, wrapw, crlf)
+        write_reads(f2, ["q%d extra/2" % i for i in range(n)], m2, r, fastq, gz, wrapw, crlf)
+        files_arg = [f1, f2]
+    else:
+        write_reads(f1, ["q%d some text" % i for i in range(n)], m1, r, fastq, gz, wrapw, crlf)
+        files_arg = [f1]
+    if r.random() < 0.5:
+        mq = float(r.choice([0.0, 10.0, 25.0]))
+        args += ["--min_quality", str(mq)]
+        kw["min_quality"] = mq
+    if r.random() < 0.3:
+        cf = int(r.choice([0, 3, 30, 130, 200]))
+        args += ["--confidence", str(cf)]
+        kw["confidence"] = cf
+    extract = r.random() < 0.25
+    if extract:
+        nfit = int(r.choice([5, 20, 50]))
+        args += ["--extract", cats[0], "--num_reads_to_fit", str(nfit), "--prefix", os.path.join(d, "ex")]
+        kw.update(run_extract=True, num_reads_to_fit=nfit)
+    want = oidx.dehost_files(files_arg[0], files_arg[1] if paired else "", **kw)
+    env = dict(os.environ)
+    env["CHARON_BATCH_READS"] = str(int(r.choice([1, 7, 64, 1000, 65536])))
+    threads = int(r.choice([1, 3, 8]))
+    p = subprocess.run([EXE, "dehost", "--db", os.path.join(d, "x.idx"), "-t", str(threads), "--log", os.path.join(d, "log")] + args + files_arg,
+                       cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert_same_tsv(p.stdout.decode() if p.stdout else "", want) if (want.strip() or p.stdout.strip()) else None
+    oidx.free()
+    return "k=%d w=%d files=%d cats=%d n=%d lmax=%d paired=%d fastq=%d gz=%d wrap=%d crlf=%d extract=%d batch=%s t=%d rows=%d" % (
+        k, w, nfiles, len(cats), n, lmax, paired, fastq, gz, wrapw, crlf, extract, env["CHARON_BATCH_READS"], threads, len(want.strip().split("\n")) if want.strip() else 0)
+
+
+def main():
+    secs, seed = float(sys.argv[1]), int(sys.argv[2])
+    po.build()
+    r = np.random.default_rng(seed)
+    t0, t = time.time(), 0
+    while time.time() - t0 < secs:
+        d = tempfile.mkdtemp(prefix="chfz")
+        try:
+            msg = trial(r, d)
+        except Exception:
+            keep = os.path.join(ROOT, "gpurun_out", "fuzz_cli_fail_%d_%d" % (seed, t))
+            shutil.copytree(d, keep, dirs_exist_ok=True)
+            print("FAILURE in trial %d (seed %d); inputs kept in %s" % (t, seed, keep), flush=True)
+            raise
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+        print("trial %d ok  %s  [%.0fs]" % (t, msg, time.time() - t0), flush=True)
+        t += 1
+    print("fuzz_cli: %d trials, no mismatch" % t)
+
+
+if __name__ == "__main__":
+    main()
