@@ -1514,7 +1514,10 @@ int index_main(IndexArguments &opt) {
     // build_index (:238-263)
     uint64_t max_hashes = 0;
     for (const auto &kv : meta.hashes_per_bin) max_hashes = std::max(max_hashes, kv.second);
-    const uint64_t S = std::max<uint64_t>(1, bin_size_in_bits(opt, max_hashes));
+    const uint64_t S = bin_size_in_bits(opt, max_hashes);
+    // no reference produced a single minimiser: seqan3's IBF constructor rejects a bin size of 0 ("The size of a bin must be > 0"),
+    // which ends the reference with an uncaught exception; fail as loudly here
+    if (S == 0) throw std::runtime_error("no minimisers in any input file: the IBF would have a bin size of 0");
     g_log.info("Create new IBF with " + std::to_string(meta.num_bins) + " bins and " + std::to_string(S) + " bits");
     meta.bins = meta.num_bins; meta.bin_words = (meta.bins + 63) / 64; meta.technical_bins = meta.bin_words * 64;
     meta.bin_size = S; meta.hash_shift = (uint64_t)__builtin_clzll(S); meta.hash_funs = opt.num_hash;

@@ -1010,6 +1010,7 @@ inline Index build_index(const std::vector<std::pair<std::string, std::string>> 
     }
     idx.summary.num_bins = bin;
     uint64_t S = force_bin_size ? force_bin_size : bin_size_in_bits(max_h, num_hash, max_fpr);
+    if (S == 0) throw std::runtime_error("The size of a bin must be > 0.");  // seqan3 interleaved_bloom_filter constructor [3P]
     idx.init_ibf(bin, S, num_hash);
     for (unsigned b = 0; b < hashes.size(); ++b)
         for (uint64_t v : hashes[b]) idx.emplace(v, b);
