@@ -58,6 +58,10 @@ def trial(r, t):
         mates = [spice(s) for s in mates]
     if not any(len(s) for s in reads):
         reads[0] = b"ACGT" * 20
+    if r.random() < 0.2:
+        msg = sharded_trial(r, oidx, reads, mates, C, paired)
+        oidx.free()
+        return "k=%d w=%d B=%d C=%d h=%d S=%d n=%d lmax=%d paired=%d %s" % (k, w, B, C, h, bin_size, n, lmax, paired, msg)
     g = util.gpu_index_from_oracle(api, oidx)
     try:
         p = pack.pack_reads(reads, mates)
@@ -73,6 +77,57 @@ def trial(r, t):
         g.destroy()
         oidx.free()
     return "k=%d w=%d B=%d C=%d h=%d S=%d n=%d lmax=%d paired=%d hashes=%d" % (k, w, B, C, h, bin_size, n, lmax, paired, int(gpu["num_hashes"].sum()))
+
+
+def sharded_trial(r, oidx, reads, mates, C, paired):
+    """row-range sharded index (chn_shard_*): N shards with random cut points on one GPU, per-shard partial probe words summed on
+    the host (what the RCCL sum all-reduce computes), every shard finishes with the total -> identical to the oracle"""
+    S, Wd, h = oidx.bin_size, oidx.bin_words, oidx.hash_funs
+    nsh = int(r.integers(2, 5))
+    cuts = sorted(set([0, S] + [int(x) for x in r.integers(1, max(S, 2), nsh - 1)]))
+    words = oidx.words()
+    host = oidx.host_index if oidx.host_index < 255 else 255
+    shards = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        d = api.make_desc(oidx.bins, S, oidx.bin_to_cat, C, host, k=oidx.k, w=oidx.w, hash_funs=h, row_begin=lo, row_end=hi)
+        sh = api.Index(d)
+        sh.upload(words[lo * Wd:hi * Wd], row_begin=lo)
+        shards.append(sh)
+    p = pack.pack_reads(reads, mates)
+    n = len(reads)
+    sts = [api.Stream(sh, n, p["n_bases"]) for sh in shards]
+    bufs = []
+    try:
+        for st in sts:
+            st.set_model(api.default_model(C, host if not paired else 0, paired=paired))
+        Es = [st.shard_minimise_host(p) for st in sts]
+        assert len(set(Es)) == 1
+        nwords = max(1, Es[0] * h * Wd)
+        bufs = [api.device_malloc(0, nwords * 8) for _ in shards]
+        for st, sh, buf in zip(sts, shards, bufs):
+            api.device_upload(0, buf, np.zeros(nwords, np.uint64))  # a batch without minimisers writes nothing into its buffer
+            st.shard_probe(sh, buf, nwords)
+        parts = [api.device_download(0, buf, nwords * 8, np.uint64) for buf in bufs]
+        total = np.zeros(nwords, np.uint64)
+        seen = np.zeros(nwords, bool)
+        for q in parts:
+            assert not np.any(seen & (q != 0)), "a probe word is non-zero in two shards"
+            seen |= q != 0
+            total += q
+        seqs, offs, split = util.concat(reads, mates)
+        orc = oidx.process_reads(seqs, offs, mate_split=split, mq_const=0.0, threads=8)
+        for st, buf in zip(sts, bufs):
+            api.device_upload(0, buf, total)
+            st.shard_finish(buf)
+            util.assert_parity(st.wait_host(), orc)
+    finally:
+        for buf in bufs:
+            api.device_free(0, buf)
+        for st in sts:
+            st.destroy()
+        for sh in shards:
+            sh.destroy()
+    return "row-sharded x%d E=%d" % (len(shards), Es[0])
 
 
 def main():
