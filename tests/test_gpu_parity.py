@@ -472,3 +472,42 @@ def test_device_elias_fano_decode(api, bins, bin_size, ones, slice_words):
                 assert not g.download().any()
             finally:
                 g.destroy()
+
+
+def test_two_streams_driven_from_two_host_threads(api, oracle_lib):
+    """one stream object is not thread-safe, but different stream objects on the same index may be driven from
+    different host threads (ctypes releases the GIL during the calls)"""
+    import threading
+    from charon_amd import pack
+    r = util.rng(77)
+    gs = [util.random_seq(r, 20000) for _ in range(3)]
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [0, 1, 1], ["host", "microbial"])
+    g = util.gpu_index_from_oracle(api, oidx)
+    batches = [util.sample_reads(r, gs, 400 + 37 * t, (50, 3000), sub_rate=0.04) for t in range(2)]
+    want = [run_oracle(oidx, b) for b in batches]
+    errors = []
+
+    def worker(t):
+        try:
+            reads = batches[t]
+            p = pack.pack_reads(reads)
+            n = len(reads)
+            st = api.Stream(g, n, p["n_bases"])
+            st.set_model(api.default_model(2, 0))
+            for _ in range(6):
+                st.submit_host(p, np.full(n, 40.0, np.float32), np.zeros(n, np.float32))
+                st.submit_host(p, np.full(n, 40.0, np.float32), np.zeros(n, np.float32))
+                util.assert_parity(st.wait_host(), want[t])
+                util.assert_parity(st.wait_host(), want[t])
+            st.destroy()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    g.destroy()
+    oidx.free()
+    assert not errors, errors
