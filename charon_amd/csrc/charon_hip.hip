@@ -1676,7 +1676,8 @@ static int submit_impl(chn_stream *s, const chn_batch *b, bool list_mode) {
         HIPCHK(hipGetLastError());
     }
     const int mode = list_mode ? MODE_LIST : fused ? MODE_FUSED : MODE_ROWS;
-    const size_t lds = k1_lds_bytes(a.wn, C, mode);
+    size_t lds = k1_lds_bytes(a.wn, C, mode);
+    if (const char *pad = std::getenv("CHN_LDS_PAD")) lds += (size_t)std::atoi(pad);  // occupancy-sensitivity diagnostic
     if (lds > 160 * 1024) return fail(CHN_E_INVALID, "window too large for LDS");
     if (prof) { HIPCHK(hipEventRecord(sl.ev[0], s->stream)); }
     hipError_t e = list_mode ? launch_k1<1, MODE_LIST>(a, lds, s->stream)
