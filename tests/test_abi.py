@@ -44,3 +44,21 @@ def test_packer_roundtrip():
     assert all(int(o) % 64 == 0 for o in p["seg1_offset"])
     back = pack.unpack_reads(p["bases2"], p["seg1_offset"], p["seg1_length"], p["nmask"])
     assert back == [b"ACGTNNACGT" * 7, b"", b"ACGTNNACGT", b"T" * 64, b"G" * 65]
+
+
+def test_no_cpu_fallback_when_the_library_is_missing(tmp_path):
+    """the product path must fail loudly without libcharon_hip.so: importing the binding from a tree that has no built library
+    raises, and nothing under charon_amd/ imports the oracle"""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = tmp_path / "charon_amd"
+    shutil.copytree(os.path.join(root, "charon_amd"), pkg, ignore=shutil.ignore_patterns("*.so", "bin", "csrc", "__pycache__"))
+    p = subprocess.run([sys.executable, "-c", "import charon_amd.api"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"not built" in p.stderr
+    for dirpath, _, files in os.walk(os.path.join(root, "charon_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".inc", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text and "charon_oracle" not in text, (dirpath, f)
