@@ -216,19 +216,69 @@ struct SdVector {
         }
         build_select();
     }
-    void build_select() {
+    void build_select() {  // word-wise: the vector of a 39 GB index has ~7e10 zeros
         sel0_samples.clear();
+        const uint64_t step = 1ULL << SAMPLE_LOG;
         uint64_t zeros = 0;
         for (uint64_t wd = 0; wd < high.size(); ++wd) {
             uint64_t z = ~high[wd];
             if (wd == high.size() - 1 && (high_bits & 63)) z &= (1ULL << (high_bits & 63)) - 1;
-            while (z) {
-                unsigned b = (unsigned)__builtin_ctzll(z);
-                if ((zeros & ((1ULL << SAMPLE_LOG) - 1)) == 0) sel0_samples.push_back(wd * 64 + b);
-                ++zeros;
-                z &= z - 1;
+            const uint64_t c = (uint64_t)__builtin_popcountll(z);
+            // zeros numbered zeros .. zeros+c-1 live in this word; the sampled ones are the multiples of `step`
+            uint64_t next = (zeros + step - 1) & ~(step - 1);
+            while (c && next < zeros + c) {
+                uint64_t t = z;
+                for (uint64_t skip = next - zeros; skip; --skip) t &= t - 1;
+                sel0_samples.push_back(wd * 64 + (unsigned)__builtin_ctzll(t));
+                next += step;
+            }
+            zeros += c;
+        }
+    }
+    // Same construction straight from the plain interleaved words, in parallel and without materialising the list of set
+    // positions (a 39 GB index holds 5e10 of them).  Threads own disjoint ranges of ones; words of `low` / `high` at range
+    // borders are shared, hence the atomic ORs.
+    void build_from_words(const std::vector<uint64_t> &plain, uint64_t universe) {
+        const uint64_t CH = 1ULL << 16, n = plain.size(), nch = (n + CH - 1) / CH;
+        std::vector<uint64_t> pre(nch + 1, 0);
+#pragma omp parallel for schedule(static)
+        for (long c = 0; c < (long)nch; ++c) {
+            uint64_t cnt = 0;
+            const uint64_t hi_w = std::min(n, ((uint64_t)c + 1) * CH);
+            for (uint64_t wd = (uint64_t)c * CH; wd < hi_w; ++wd) cnt += (uint64_t)__builtin_popcountll(plain[wd]);
+            pre[c + 1] = cnt;
+        }
+        for (uint64_t c = 0; c < nch; ++c) pre[c + 1] += pre[c];
+        size = universe;
+        ones = pre[nch];
+        unsigned logm = hi(ones) + 1, logn = hi(size) + 1;
+        if (logm == logn) --logm;
+        wl = (uint8_t)(logn - logm);
+        high_bits = ones + (1ULL << logm);
+        low.assign((ones * wl + 63) / 64 + 1, 0);
+        high.assign((high_bits + 63) / 64, 0);
+        const uint64_t mask = wl >= 64 ? ~0ULL : ((wl ? (1ULL << wl) : 1ULL) - 1);
+#pragma omp parallel for schedule(dynamic, 16)
+        for (long c = 0; c < (long)nch; ++c) {
+            uint64_t k = pre[c];
+            const uint64_t hi_w = std::min(n, ((uint64_t)c + 1) * CH);
+            for (uint64_t wd = (uint64_t)c * CH; wd < hi_w; ++wd) {
+                uint64_t x = plain[wd];
+                while (x) {
+                    const uint64_t pos = wd * 64 + (unsigned)__builtin_ctzll(x);
+                    x &= x - 1;
+                    if (wl) {
+                        const uint64_t val = pos & mask, bit = k * wl, w0 = bit >> 6, sh = bit & 63;
+                        __atomic_fetch_or(&low[w0], val << sh, __ATOMIC_RELAXED);
+                        if (sh + wl > 64) __atomic_fetch_or(&low[w0 + 1], val >> (64 - sh), __ATOMIC_RELAXED);
+                    }
+                    const uint64_t hp = (wl >= 64 ? 0 : (pos >> wl)) + k;
+                    __atomic_fetch_or(&high[hp >> 6], 1ULL << (hp & 63), __ATOMIC_RELAXED);
+                    ++k;
+                }
             }
         }
+        build_select();
     }
     // position in `high` of the j-th zero (0-based); returns high_bits if there is none
     uint64_t select0(uint64_t j) const {
@@ -335,12 +385,7 @@ struct Index {
         }
     }
     void compress() {  // uncompressed -> compressed conversion of include/index.hpp:43-50
-        std::vector<uint64_t> pos;
-        for (uint64_t wd = 0; wd < plain.size(); ++wd) {
-            uint64_t x = plain[wd];
-            while (x) { pos.push_back(wd * 64 + (unsigned)__builtin_ctzll(x)); x &= x - 1; }
-        }
-        ef.build(pos.begin(), pos.end(), technical_bins * bin_size);
+        ef.build_from_words(plain, technical_bins * bin_size);
         has_ef = true;
     }
     void decompress() {
