@@ -338,7 +338,8 @@ def cpu_baseline(api, index, reads, res, n_reads, args, device, categories, b2c)
     # at -t 1 and -t N.  The oracle builds its sd_vector straight from the downloaded plain words, in parallel (39 GB plain ->
     # ~35 GB compressed, next to the plain copy in host memory).
     faithful = None
-    if d.bin_size * d.bin_words * 8 <= (64 << 30):
+    # building the sd_vector of a 39 GB index takes ~40 s on 64 host threads; with a small CPU share it would dominate the run
+    if d.bin_size * d.bin_words * 8 <= (2 << 30) or (d.bin_size * d.bin_words * 8 <= (64 << 30) and threads >= 32):
         t0 = time.perf_counter()
         oidx.compress()
         oidx.use_ef(True)
