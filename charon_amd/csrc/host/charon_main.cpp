@@ -47,12 +47,17 @@
 #endif
 
 #include "charon_hip.h"
+#include "gzip_size.hpp"
 
 #ifndef CHARON_VERSION
 #define CHARON_VERSION "charon-mi355x 0.1.0 (reference behaviour: rmcolq/charon @ 2025-07-04)"
 #endif
 
 namespace {
+
+// gzip column: bit-exact size emulator (host/gzip_size.hpp) unless CHARON_ZLIB_ONLY is set or the start-up cross-check against
+// the linked zlib fails
+bool g_gzip_emulator = true;
 
 #include "log_util.inc"
 #include "dehost_args.inc"
@@ -74,6 +79,24 @@ int main(int argc, char **argv) {
                      "  dehost   Dehost read file into host and other using index.\n"
                      "  (classify is not part of the MI355X hot-path build)\n";
         return 0;
+    }
+    if (sub == "_gzsize") {  // hidden diagnostic: per record, gzip size by the linked zlib and by the size emulator (no GPU involved)
+        try {
+            if (argc < 3) return 2;
+            BlockReader in(argv[2]);
+            RawBlock blk;
+            Deflater d;
+            std::cout << "selfcheck\t" << (gzip_emulator_self_check() ? 1 : 0) << "\n";
+            while (in.next(blk, 1000, 1u << 24))
+                for (const RecView &r : blk.recs) {
+                    if (r.seq_len == 0) continue;
+                    d.load(r, nullptr);
+                    const size_t n = r.seq_len;
+                    const uint32_t e = n <= gzsize::GzipSizer::MAX_BYTES ? d.sizer.size_padded(reinterpret_cast<const uint8_t *>(d.up.data()), n) : 0;
+                    std::cout << std::string(r.id, r.id_len) << "\t" << d.zlib_size(n) << "\t" << e << "\n";
+                }
+            return 0;
+        } catch (std::exception &e) { std::cerr << "charon: " << e.what() << std::endl; return 1; }
     }
     if (sub == "_records") {  // hidden diagnostic: dump what the block reader sees (no GPU involved)
         try {

@@ -99,3 +99,47 @@ def test_block_reader_sees_what_was_written(tmp_path):
             got = out.strip("\n").split("\n")
             assert got == (want_fq if fastq else want_fa), (name, max_recs, max_bytes)
     # an empty-sequence FASTA record is legal; an illegal letter is only detected when packing (dehost), not here
+
+
+def test_gzip_size_emulator_equals_the_linked_zlib(tmp_path):
+    """the `compression` column (src/utils.cpp:114-124) is computed by a size-only restatement of zlib's level-6 deflate
+    (charon_amd/csrc/host/gzip_size.hpp); it must give exactly the size the linked zlib gives, record by record (hidden `_gzsize`
+    diagnostic, no GPU).  tools/gzip_size_check.cpp is the larger sweep (480 k cases clean in round 1)."""
+    import numpy as np
+    r = np.random.default_rng(5)
+    recs = []
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    for i in range(600):
+        L = int(r.choice([1, 2, 3, 4, 7, 19, 41, 150, 300, 1000, 5000, 5000, 5000, 20000, 59999, 60000]))
+        if i % 7 == 0:
+            L = int(r.integers(1, 3000))
+        s = acgt[r.integers(0, 4, L)].copy()
+        kind = i % 6
+        if kind == 1:
+            s[r.random(L) < 0.03] = ord("N")
+        elif kind == 2 and L > 20:
+            unit = acgt[r.integers(0, 4, int(r.integers(1, 9)))]
+            s = np.resize(unit, L)
+        elif kind == 3 and L > 200:
+            for _ in range(10):
+                a, b, ln = int(r.integers(0, L)), int(r.integers(0, L)), int(r.integers(10, 400))
+                ln = min(ln, L - a, L - b)
+                s[b:b + ln] = s[a:a + ln].copy()
+        elif kind == 4:
+            s[:] = acgt[int(r.integers(0, 4))]
+        elif kind == 5 and L > 10:
+            s = np.frombuffer(bytes(s).lower(), np.uint8).copy()
+            s[3] = ord("r")  # IUPAC -> N
+        recs.append(bytes(s))
+    path = tmp_path / "z.fa"
+    with open(path, "wb") as f:
+        for i, s in enumerate(recs):
+            f.write(b">s%d\n" % i + s + b"\n")
+    rc, out, err = run(["_gzsize", str(path)])
+    assert rc == 0, err
+    lines = out.strip().split("\n")
+    assert lines[0] == "selfcheck\t1"
+    assert len(lines) == 1 + len(recs)
+    for ln in lines[1:]:
+        name, z, e = ln.split("\t")
+        assert z == e, ln

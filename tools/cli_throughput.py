@@ -40,16 +40,25 @@ def main():
             f.write(b"@r%d\n%s\n+\n%s\n" % (i, util.mutate(r, g[s:s + 5000], 0.05), qual))
     print("fastq: %d reads, %.2f GB, written in %.1fs" % (n, os.path.getsize(fq) / 1e9, time.time() - t0), flush=True)
     exe = os.path.join(ROOT, "charon_amd", "bin", "charon")
-    for t in (1, 16, 64):
-        t0 = time.time()
-        p = subprocess.run([exe, "dehost", "--db", os.path.join(work, "bench.idx"), "-t", str(t), "--log", os.path.join(work, "c.log"), fq],
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        dt = time.time() - t0
-        rows = p.stdout.count(b"\n")
-        cls = sum(1 for line in p.stdout.split(b"\n") if line.startswith(b"C\t"))
-        print("charon dehost -t %d: rc=%d rows=%d classified=%d  %.2fs  -> %.0f reads/s" % (t, p.returncode, rows, cls, dt, n / dt), flush=True)
-        if p.returncode:
-            print(p.stderr.decode()[-500:])
+    ref = None
+    for label, extra in (("gzip column by the size emulator (default)", {}), ("gzip column by zlib (CHARON_ZLIB_ONLY=1)", {"CHARON_ZLIB_ONLY": "1"}),
+                         ("no gzip column (CHARON_SKIP_COMPRESSION=1)", {"CHARON_SKIP_COMPRESSION": "1"})):
+        print(label, flush=True)
+        for t in (1, 16, 64):
+            t0 = time.time()
+            p = subprocess.run([exe, "dehost", "--db", os.path.join(work, "bench.idx"), "-t", str(t), "--log", os.path.join(work, "c.log"), fq],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **extra))
+            dt = time.time() - t0
+            rows = p.stdout.count(b"\n")
+            cls = sum(1 for line in p.stdout.split(b"\n") if line.startswith(b"C\t"))
+            same = ""
+            if "SKIP" not in "".join(extra):
+                if ref is None:
+                    ref = p.stdout
+                same = "  identical TSV: %s" % (p.stdout == ref)
+            print("  charon dehost -t %d: rc=%d rows=%d classified=%d  %.2fs  -> %.0f reads/s%s" % (t, p.returncode, rows, cls, dt, n / dt, same), flush=True)
+            if p.returncode:
+                print(p.stderr.decode()[-500:])
 
 
 if __name__ == "__main__":
