@@ -118,9 +118,25 @@ private:
         if (!dna_tab_) {
             std::memset(dna_code_, -1, sizeof dna_code_);
             dna_code_[(int)'A'] = 0; dna_code_[(int)'C'] = 1; dna_code_[(int)'G'] = 2; dna_code_[(int)'T'] = 3; dna_code_[(int)'N'] = 4;
-            cnt_.assign(HASH_SIZE, 0); last3_.assign(1u << 9, 0); last4_.assign(1u << 12, 0); last5_.assign(1u << 15, 0); last6_.assign(1u << 18, 0);
+            // base-5 k-mer keys keep the tables small (125 / 625 / 3 125 / 15 625 entries): they stay cache-resident for short reads.
+            // The 15-bit zlib hash separates all 125 DNA trigrams (checked here), so a hash class IS a trigram class.
+            bool distinct = true;
+            {
+                std::vector<uint8_t> seen(HASH_SIZE, 0);
+                const char *al = "ACGTN";
+                for (int a = 0; a < 5; ++a) for (int b = 0; b < 5; ++b) for (int c = 0; c < 5; ++c) {
+                    const uint8_t t[3] = {(uint8_t)al[a], (uint8_t)al[b], (uint8_t)al[c]};
+                    uint8_t &sv = seen[hash3(t)];
+                    if (sv) distinct = false;
+                    sv = 1;
+                }
+            }
+            dna_ok_ = distinct;
+            cnt_.assign(125, 0); last3_.assign(125, 0); last4_.assign(625, 0); last5_.assign(3125, 0); last6_.assign(15625, 0);
             dna_tab_ = true;
         }
+        dna_ = false;
+        if (!dna_ok_) return false;
         if (++epoch_ == 0x10000u) {
             std::fill(cnt_.begin(), cnt_.end(), 0u); std::fill(last3_.begin(), last3_.end(), 0u); std::fill(last4_.begin(), last4_.end(), 0u);
             std::fill(last5_.begin(), last5_.end(), 0u); std::fill(last6_.begin(), last6_.end(), 0u);
@@ -128,34 +144,40 @@ private:
         }
         const uint32_t tag = epoch_ << 16;
         if (rank16_.size() < n + 8) { rank16_.resize(n + 8); prev3_.resize(n + 8); prev4_.resize(n + 8); prev5_.resize(n + 8); prev6_.resize(n + 8); }
-        dna_ = false;
-        uint32_t k = 0;
         const uint8_t *d = in_;
+        uint32_t k3 = 0, k4 = 0, k5 = 0, k6 = 0;  // base-5 keys of the 3/4/5/6-mers ENDING at the current byte
+        uint32_t hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // the last codes, by position & 7 (zero before the start)
         for (size_t e = 0; e < n; ++e) {
-            const int c = dna_code_[d[e]];
-            if (c < 0) return false;
-            k = ((k << 3) | (uint32_t)c) & ((1u << 18) - 1);
+            const int ci = dna_code_[d[e]];
+            if (ci < 0) return false;
+            const uint32_t c = (uint32_t)ci;
+            // the digit that leaves a window of length L is the code at e - L
+            k3 = (k3 - hist[(e + 5) & 7] * 25u) * 5u + c;
+            k4 = (k4 - hist[(e + 4) & 7] * 125u) * 5u + c;
+            k5 = (k5 - hist[(e + 3) & 7] * 625u) * 5u + c;
+            k6 = (k6 - hist[(e + 2) & 7] * 3125u) * 5u + c;
+            hist[e & 7] = c;
             if (e >= 2) {
                 const size_t p = e - 2;
-                uint32_t &ct = cnt_[hash3(d + p)];
+                uint32_t &ct = cnt_[k3];
                 if ((ct & 0xffff0000u) != tag) ct = tag;
                 rank16_[p] = (uint16_t)ct;
                 ++ct;
-                uint32_t &l3 = last3_[k & 0x1ff];
+                uint32_t &l3 = last3_[k3];
                 prev3_[p] = (l3 & 0xffff0000u) == tag ? (uint16_t)l3 : (uint16_t)0;
                 l3 = tag | (uint32_t)(p + 1);
                 if (e >= 3) {
-                    uint32_t &l4 = last4_[k & 0xfff];
+                    uint32_t &l4 = last4_[k4];
                     prev4_[p - 1] = (l4 & 0xffff0000u) == tag ? (uint16_t)l4 : (uint16_t)0;
                     l4 = tag | (uint32_t)p;
                 }
                 if (e >= 4) {
-                    uint32_t &l5 = last5_[k & 0x7fff];
+                    uint32_t &l5 = last5_[k5];
                     prev5_[p - 2] = (l5 & 0xffff0000u) == tag ? (uint16_t)l5 : (uint16_t)0;
                     l5 = tag | (uint32_t)(p - 1);
                 }
                 if (e >= 5) {
-                    uint32_t &l6 = last6_[k];
+                    uint32_t &l6 = last6_[k6];
                     prev6_[p - 3] = (l6 & 0xffff0000u) == tag ? (uint16_t)l6 : (uint16_t)0;
                     l6 = tag | (uint32_t)(p - 2);
                 }
@@ -169,6 +191,7 @@ private:
         dna_ = true;
         return true;
     }
+    bool dna_ok_ = false;
 
     static inline uint16_t ld16(const uint8_t *p) { uint16_t v; std::memcpy(&v, p, 2); return v; }
     static inline uint64_t ld64(const uint8_t *p) { uint64_t v; std::memcpy(&v, p, 8); return v; }

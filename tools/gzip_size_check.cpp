@@ -39,7 +39,9 @@ int main(int argc, char **argv) {
         size_t L;
         const bool only5k = std::getenv("ONLY5K") != nullptr;
         if (only5k) kind = 0;
-        switch (only5k ? 3 : rng() % 8) {
+        const char *fixed = std::getenv("FIXEDLEN");
+        switch (only5k ? 3 : fixed ? 9 : rng() % 8) {
+            case 9: L = (size_t)std::atol(fixed); kind = 0; break;
             case 0: L = 1 + rng() % 40; break;
             case 1: L = 1 + rng() % 400; break;
             case 2: L = 100 + rng() % 300; break;
