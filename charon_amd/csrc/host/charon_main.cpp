@@ -92,7 +92,7 @@ int main(int argc, char **argv) {
                     if (r.seq_len == 0) continue;
                     d.load(r, nullptr);
                     const size_t n = r.seq_len;
-                    const uint32_t e = n <= gzsize::GzipSizer::MAX_BYTES ? d.sizer.size_padded(reinterpret_cast<const uint8_t *>(d.up.data()), n) : 0;
+                    const uint32_t e = d.sizer.size_padded(reinterpret_cast<const uint8_t *>(d.up.data()), n);
                     std::cout << std::string(r.id, r.id_len) << "\t" << d.zlib_size(n) << "\t" << e << "\n";
                 }
             return 0;

@@ -18,8 +18,9 @@
 // its hash class; if there is none, the answer is the most recent occurrence of the 5-, 4- or 3-mer inside E.  Same result, a
 // fraction of the work.
 //
-// Scope: inputs of 1..GzipSizer::MAX_BYTES bytes, all < 128 (the dna5 letters are).  Longer inputs would need zlib's window
-// sliding; the caller uses zlib for those.
+// Scope: A/C/G/T/N inputs of any length up to 1 GiB (zlib's window slide -- fill_window / slide_hash -- is emulated: the window
+// base advances by w_size whenever strstart passes w_size + MAX_DIST, positions at or below the base are NIL); other 7-bit inputs
+// up to GzipSizer::MAX_BYTES through the generic candidate loop.  size() returns 0 for anything else and the caller uses zlib.
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -29,11 +30,12 @@ namespace gzsize {
 
 class GzipSizer {
 public:
-    static const size_t MAX_BYTES = 60000;  // the whole input must fit zlib's 64 KiB window without a slide
+    static const size_t MAX_BYTES = 60000;          // generic (non-DNA) inputs: the whole input must fit zlib's 64 KiB window without a slide
+    static const size_t MAX_DNA_BYTES = 1u << 30;   // A/C/G/T/N inputs: the window slide is emulated
 
     // total bytes of the gzip member (10-byte header + deflate stream + 8-byte trailer); 0 if the input is out of scope
     uint32_t size(const uint8_t *data, size_t n) {
-        if (n == 0 || n > MAX_BYTES) return 0;
+        if (n == 0 || n > MAX_DNA_BYTES) return 0;
         buf_.assign(n + PAD, 0);
         std::memcpy(buf_.data(), data, n);
         return size_padded(buf_.data(), n);
@@ -41,9 +43,10 @@ public:
     // same, for a caller whose buffer already has PAD zero bytes behind the n data bytes (no copy)
     static const size_t PAD = 258 + 16;
     uint32_t size_padded(const uint8_t *data, size_t n) {
-        if (n == 0 || n > MAX_BYTES) return 0;
+        if (n == 0 || n > MAX_DNA_BYTES) return 0;
         in_ = data;
         if (!prepare_dna(n)) {
+            if (n > MAX_BYTES) return 0;  // the generic path does not emulate the window slide
             for (size_t i = 0; i < n; ++i)
                 if (data[i] & 0x80) return 0;
             prepare(n);
@@ -109,9 +112,9 @@ private:
     // fast path: rank of each position inside its hash class and the previous occurrence (+1, 0 = none) of the 3/4/5/6-mer starting
     // there.  The tables are epoch-tagged (high 16 bits) so nothing has to be cleared between reads; positions fit 16 bits.
     bool dna_ = false;
-    std::vector<uint16_t> rank16_, prev3_, prev4_, prev5_, prev6_;
-    std::vector<uint32_t> cnt_, last3_, last4_, last5_, last6_;
-    uint32_t epoch_ = 0;
+    std::vector<uint32_t> rank16_, prev3_, prev4_, prev5_, prev6_;
+    std::vector<uint64_t> cnt_, last3_, last4_, last5_, last6_;
+    uint64_t epoch_ = 0;
     int8_t dna_code_[256];
     bool dna_tab_ = false;
     bool prepare_dna(size_t n) {
@@ -137,12 +140,8 @@ private:
         }
         dna_ = false;
         if (!dna_ok_) return false;
-        if (++epoch_ == 0x10000u) {
-            std::fill(cnt_.begin(), cnt_.end(), 0u); std::fill(last3_.begin(), last3_.end(), 0u); std::fill(last4_.begin(), last4_.end(), 0u);
-            std::fill(last5_.begin(), last5_.end(), 0u); std::fill(last6_.begin(), last6_.end(), 0u);
-            epoch_ = 1;
-        }
-        const uint32_t tag = epoch_ << 16;
+        ++epoch_;  // tables are tagged with the call number (high 32 bits): nothing is cleared between reads
+        const uint64_t tag = epoch_ << 32;
         if (rank16_.size() < n + 8) { rank16_.resize(n + 8); prev3_.resize(n + 8); prev4_.resize(n + 8); prev5_.resize(n + 8); prev6_.resize(n + 8); }
         const uint8_t *d = in_;
         uint32_t k3 = 0, k4 = 0, k5 = 0, k6 = 0;  // base-5 keys of the 3/4/5/6-mers ENDING at the current byte
@@ -159,27 +158,27 @@ private:
             hist[e & 7] = c;
             if (e >= 2) {
                 const size_t p = e - 2;
-                uint32_t &ct = cnt_[k3];
-                if ((ct & 0xffff0000u) != tag) ct = tag;
-                rank16_[p] = (uint16_t)ct;
+                uint64_t &ct = cnt_[k3];
+                if ((ct >> 32) != epoch_) ct = tag;
+                rank16_[p] = (uint32_t)ct;
                 ++ct;
-                uint32_t &l3 = last3_[k3];
-                prev3_[p] = (l3 & 0xffff0000u) == tag ? (uint16_t)l3 : (uint16_t)0;
-                l3 = tag | (uint32_t)(p + 1);
+                uint64_t &l3 = last3_[k3];
+                prev3_[p] = (l3 >> 32) == epoch_ ? (uint32_t)l3 : 0u;
+                l3 = tag | (uint64_t)(p + 1);
                 if (e >= 3) {
-                    uint32_t &l4 = last4_[k4];
-                    prev4_[p - 1] = (l4 & 0xffff0000u) == tag ? (uint16_t)l4 : (uint16_t)0;
-                    l4 = tag | (uint32_t)p;
+                    uint64_t &l4 = last4_[k4];
+                    prev4_[p - 1] = (l4 >> 32) == epoch_ ? (uint32_t)l4 : 0u;
+                    l4 = tag | (uint64_t)p;
                 }
                 if (e >= 4) {
-                    uint32_t &l5 = last5_[k5];
-                    prev5_[p - 2] = (l5 & 0xffff0000u) == tag ? (uint16_t)l5 : (uint16_t)0;
-                    l5 = tag | (uint32_t)(p - 1);
+                    uint64_t &l5 = last5_[k5];
+                    prev5_[p - 2] = (l5 >> 32) == epoch_ ? (uint32_t)l5 : 0u;
+                    l5 = tag | (uint64_t)(p - 1);
                 }
                 if (e >= 5) {
-                    uint32_t &l6 = last6_[k6];
-                    prev6_[p - 3] = (l6 & 0xffff0000u) == tag ? (uint16_t)l6 : (uint16_t)0;
-                    l6 = tag | (uint32_t)(p - 2);
+                    uint64_t &l6 = last6_[k6];
+                    prev6_[p - 3] = (l6 >> 32) == epoch_ ? (uint32_t)l6 : 0u;
+                    l6 = tag | (uint64_t)(p - 2);
                 }
             }
         }
@@ -198,6 +197,7 @@ private:
 
     // ---- longest_match (deflate.c), same candidates in the same order ------------------------------------------------
     uint32_t match_start_ = 0;
+    uint32_t base_ = 0;  // absolute position of the window start (multiples of w_size; 0 until the first slide)
     uint32_t longest_match(uint32_t strstart, uint32_t lookahead, uint32_t prev_length) {
         uint32_t chain_length = MAX_CHAIN;
         uint32_t best_len = prev_length;
@@ -241,13 +241,16 @@ private:
     uint32_t longest_match_dna(uint32_t strstart, uint32_t lookahead, uint32_t prev_length) {
         const uint32_t K = prev_length >= (uint32_t)GOOD_MATCH ? (uint32_t)MAX_CHAIN >> 2 : (uint32_t)MAX_CHAIN;
         const uint32_t nice_match = (uint32_t)NICE_MATCH > lookahead ? lookahead : (uint32_t)NICE_MATCH;
-        const uint32_t limit = strstart > (uint32_t)MAX_DIST ? strstart - (uint32_t)MAX_DIST : 0;
+        // limit = strstart > MAX_DIST ? strstart - MAX_DIST : NIL, in window-relative positions; NIL is the window base
+        const uint32_t limit = strstart - base_ > (uint32_t)MAX_DIST ? strstart - (uint32_t)MAX_DIST : base_;
         const uint32_t rs = rank16_[strstart];
         uint32_t best_len = prev_length;
         const uint8_t *scan = in_ + strstart;
         auto in_e = [&](uint32_t c) {
-            const uint32_t d = (uint32_t)(uint16_t)(rs - rank16_[c]);
-            return c != 0 && d <= K && (c > limit || (d == 1 && c >= limit));
+            const uint32_t d = rs - rank16_[c];  // 1 = the head of the chain
+            if (d > K) return false;
+            // the head was vetted by the caller (not NIL, within MAX_DIST); the others must lie above the limit
+            return d == 1 ? (c > base_ && strstart - c <= (uint32_t)MAX_DIST) : c > limit;
         };
         bool any6 = false;
         for (uint32_t c1 = prev6_[strstart]; c1 != 0; c1 = prev6_[c1 - 1]) {
@@ -452,7 +455,7 @@ private:
     uint8_t static_llen_[L_CODES + 2], static_dlen_[D_CODES];
 
     // _tr_flush_block: adds the bits of this block to total_bits_
-    void flush_block(uint64_t stored_len, bool last) {
+    void flush_block(uint64_t stored_len, bool last, bool buf_available = true) {
         TreeDesc ld = {lfreq_, static_llen_, extra_lbits(), LITERALS + 1, L_CODES, MAX_BITS, -1};
         TreeDesc dd = {dfreq_, static_dlen_, extra_dbits(), 0, D_CODES, MAX_BITS, -1};
         TreeDesc bd = {blfreq_, nullptr, extra_blbits(), 0, BL_CODES, MAX_BL_BITS, -1};
@@ -469,7 +472,7 @@ private:
         uint64_t opt_lenb = (opt_len_ + 3 + 7) >> 3;
         const uint64_t static_lenb = (static_len_ + 3 + 7) >> 3;
         if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
-        if (stored_len + 4 <= opt_lenb) {
+        if (stored_len + 4 <= opt_lenb && buf_available) {
             // _tr_stored_block: 3 header bits, pad to a byte, LEN + NLEN, the bytes
             total_bits_ += 3;
             total_bits_ = (total_bits_ + 7) & ~7ULL;
@@ -499,15 +502,25 @@ private:
         uint32_t strstart = 0, block_start = 0, match_length = MIN_MATCH - 1, prev_length, prev_match;
         bool match_available = false;
         match_start_ = 0;
+        base_ = 0;
+        uint32_t loaded_end = n < 2u * W_SIZE ? n : 2u * W_SIZE;  // the first fill_window reads as much as the window holds
         for (;;) {
-            const uint32_t lookahead = n - strstart;
+            if (loaded_end - strstart < (uint32_t)MIN_LOOKAHEAD) {
+                // fill_window: slide the window by w_size once strstart has passed w_size + MAX_DIST (even when no input is left),
+                // then read as much as fits
+                if (strstart - base_ >= (uint32_t)(W_SIZE + MAX_DIST)) base_ += W_SIZE;
+                const uint64_t cap = (uint64_t)base_ + 2u * W_SIZE;
+                loaded_end = n < cap ? n : (uint32_t)cap;
+            }
+            const uint32_t lookahead = loaded_end - strstart;
             if (lookahead == 0) break;
             uint32_t hash_head = 0;  // NIL
             if (lookahead >= (uint32_t)MIN_MATCH) {
                 if (dna_) {
                     // zlib only asks whether the class has an earlier member and how far the most recent one is; for DNA letters the
                     // 15-bit hash separates all 125 trigrams, so that member is the previous occurrence of the trigram
-                    hash_head = prev3_[strstart] ? (uint32_t)prev3_[strstart] - 1 : 0;
+                    hash_head = prev3_[strstart] ? prev3_[strstart] - 1 : 0;
+                    if (hash_head <= base_) hash_head = 0;  // slide_hash turned everything at or below the window base into NIL
                 } else {
                     const uint32_t r = rank_[strstart];
                     if (r > cls_lo_[strstart]) hash_head = occ_[r - 1];  // the previous position of the same hash class (0 == NIL, as in zlib)
@@ -516,7 +529,7 @@ private:
             prev_length = match_length;
             prev_match = match_start_;
             match_length = MIN_MATCH - 1;
-            if (hash_head != 0 && prev_length < (uint32_t)MAX_LAZY && strstart - hash_head <= (uint32_t)MAX_DIST) {
+            if (hash_head != 0 && prev_length < (uint32_t)MAX_LAZY && strstart - hash_head <= (uint32_t)MAX_DIST) {  // hash_head != NIL
                 match_length = dna_ ? longest_match_dna(strstart, lookahead, prev_length) : longest_match(strstart, lookahead, prev_length);
                 if (match_length <= 5 && (match_length == (uint32_t)MIN_MATCH && strstart - match_start_ > (uint32_t)TOO_FAR)) match_length = MIN_MATCH - 1;
             }
@@ -525,10 +538,10 @@ private:
                 strstart += prev_length - 1;  // the strings up to the end of the match enter the dictionary (implicit here)
                 match_available = false;
                 match_length = MIN_MATCH - 1;
-                if (bflush) { flush_block(strstart - block_start, false); block_start = strstart; }
+                if (bflush) { flush_block(strstart - block_start, false, block_start >= base_); block_start = strstart; }
             } else if (match_available) {
                 const bool bflush = tally_lit(in_[strstart - 1]);
-                if (bflush) { flush_block(strstart - block_start, false); block_start = strstart; }
+                if (bflush) { flush_block(strstart - block_start, false, block_start >= base_); block_start = strstart; }
                 strstart++;
             } else {
                 match_available = true;
@@ -536,7 +549,7 @@ private:
             }
         }
         if (match_available) tally_lit(in_[strstart - 1]);
-        flush_block(strstart - block_start, true);
+        flush_block(strstart - block_start, true, block_start >= base_);
     }
 };
 
