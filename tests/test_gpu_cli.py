@@ -291,3 +291,24 @@ def test_cli_rejects_corrupted_index_payload(tmp_path):
     assert any(rc != 0 for rc, _ in outcomes), outcomes
     for rc, msg in outcomes:
         assert rc != 0 or "self-check" in open(tmp_path / "charon.log").read(), outcomes
+
+
+def test_cli_long_reads_compression_column(tmp_path, oracle_lib):
+    """reads longer than zlib's 32 KiB window: the gzip-size emulator has to reproduce zlib's window slide; the TSV (incl. the
+    compression column, which the oracle computes with zlib itself) must still be identical, in both modes of the front end"""
+    r = util.rng(808)
+    gs = [util.random_seq(r, 200000), util.random_seq(r, 200000)]
+    oidx = util.build_oracle_index(oracle_lib, [[gs[0]], [gs[1]]], [0, 1], ["host", "microbial"])
+    oidx.compress()
+    oidx.store(str(tmp_path / "l.idx"))
+    reads = [util.mutate(r, gs[0][100:70100], 0.05), util.mutate(r, gs[1][:150000], 0.08), gs[0][5000:10000], b"ACGT" * 20000,
+             util.mutate(r, gs[1][1000:66300], 0.02), gs[0][:65274] + b"N" * 40]
+    with open(tmp_path / "long.fastq", "w") as f:
+        for i, s in enumerate(reads):
+            f.write("@L%d\n%s\n+\n%s\n" % (i, s.decode(), "I" * len(s)))
+    want = oidx.dehost_files(str(tmp_path / "long.fastq"))
+    for env in ({}, {"CHARON_ZLIB_ONLY": "1"}):
+        rc, out, err = run_cli(["--db", str(tmp_path / "l.idx"), "-t", "4", str(tmp_path / "long.fastq")], str(tmp_path), env)
+        assert rc == 0, err
+        assert_same_tsv(out, want)
+    oidx.free()
