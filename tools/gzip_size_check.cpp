@@ -26,6 +26,23 @@ struct Z {
 };
 
 int main(int argc, char **argv) {
+    if (argc > 1 && std::string(argv[1]) == "exhaustive") {
+        // every string over {A,C,G,T,N} up to length 8 (488 280 strings) and every ACGT string of length 9..10
+        Z z0; gzsize::GzipSizer g0; long bad0 = 0, n0 = 0;
+        const char *al = "ACGTN";
+        for (int L = 1; L <= 10; ++L) {
+            const int base = L <= 8 ? 5 : 4;
+            long total = 1; for (int i = 0; i < L; ++i) total *= base;
+            std::string s(L, 'A');
+            for (long v = 0; v < total; ++v) {
+                long x = v; for (int i = 0; i < L; ++i) { s[i] = al[x % base]; x /= base; }
+                ++n0;
+                if (z0.size(s) != g0.size(reinterpret_cast<const uint8_t *>(s.data()), s.size())) { if (++bad0 <= 10) std::printf("MISMATCH %s\n", s.c_str()); }
+            }
+        }
+        std::printf("exhaustive: %ld strings, %ld mismatches\n", n0, bad0);
+        return bad0 ? 1 : 0;
+    }
     const long cases = argc > 1 ? std::atol(argv[1]) : 20000;
     std::mt19937_64 rng(argc > 2 ? std::atoll(argv[2]) : 1);
     Z z;
