@@ -10,9 +10,17 @@ over one batch of synthetic reads that is already resident in HBM.  Workloads (S
   cfg2  5 kb reads vs the 2-category 1 GiB index (B=2, W=1, S=2^27)  -- BASELINE configs[1]
   small tiny smoke-sized variant of cfg2 (CPU-container rehearsal of the harness is impossible: needs a GPU)
 
-Multi-GPU (`--gpus N`, launched by torch.distributed.run): the 39 GB index fits every GPU, so the path shards by
-READ with a full index replica per rank and no data-path collective ("weak" scaling: per-GPU batch fixed).  The
-only collective is the barrier / max-reduce of the timing contract and one all-reduce of the summary counters.
+Multi-GPU (`--gpus N`): the 39 GB index fits every GPU, so the path shards by READ with a full index replica per rank
+and no data-path collective ("weak" scaling: per-GPU batch fixed).  The only collective is the barrier / max-reduce of
+the timing contract and one all-reduce of the summary counters.  Started under torch.distributed.run (WORLD_SIZE set)
+this process is one rank; started plainly with --gpus N > 1 it launches the N ranks itself (before touching the GPU)
+and relays rank 0's JSON line.
+
+What is timed: the device chain on packed reads that are ALREADY RESIDENT IN HBM (`config.input`); FASTQ parsing, the
+mean-quality and gzip-ratio columns are host work outside the timed region.  The host-buffer entry (H2D of the packed
+batch + D2H of the results, pinned memory, two batches in flight) is timed separately and reported as
+`config.pcie_inclusive_reads_per_s` -- it is never `value`.  Steps cycle through `--read-sets` distinct read sets so that no
+step replays the previous step's batch (the model kernel's memo table sees new keys, as in a real run).
 
 Prints ONE JSON line on rank 0.
 """
@@ -61,18 +69,30 @@ def main():
                     help="reads (default): full index replica per rank, reads sharded, no data-path collective; "
                          "rows: index row-range sharded over ranks, every rank minimises the same batch, one RCCL sum "
                          "all-reduce of the probe words per batch (for indexes that do not fit one GPU)")
-    ap.add_argument("--pcie", action="store_true", help="also time the host-buffer entry (H2D of the packed batch + D2H of the results)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer leg (H2D of the packed batch + D2H of the results)")
+    ap.add_argument("--read-sets", type=int, default=3, help="distinct synthetic read sets the steps cycle through")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rehearse the launch / rendezvous / timing-reduction plumbing only (no GPU work; CPU test of --gpus N)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    ndev = torch.cuda.device_count()
+    use_dist = "WORLD_SIZE" in os.environ  # launched by torch.distributed.run (also with one rank: same RCCL code path)
+    ndev = torch.cuda.device_count()       # does not initialise the GPU
+    if args.launch_check:
+        return launch_check(args, rank, world, use_dist)
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
+    if args.backend == "nccl" and world > ndev:
+        raise SystemExit("bench.py: %d ranks on %d GPU(s) -- RCCL needs one GPU per rank (use --backend gloo only to rehearse the "
+                         "launch on fewer GPUs; such a run is labelled \"rehearsal\" and is not a scaling figure)" % (world, ndev))
+    rehearsal = world > ndev or (args.backend == "gloo" and world > 1)
     dev = local % ndev  # == local on a real N-GPU launch; wraps only in a gloo rehearsal on fewer GPUs
-    use_dist = "WORLD_SIZE" in os.environ  # launched by torch.distributed.run (also with one rank: same RCCL code path)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -115,23 +135,33 @@ def main():
     index.synth_fill(43, wl["fill"])
     genomes = api.synth_genomes(local, 43, B, wl["genome_len"])
     index.synth_plant(genomes, B, wl["genome_len"], list(range(B)))
-    # weak scaling: rank r classifies global reads [r*n, (r+1)*n) of one seeded read set (charon_amd/shard.py)
-    lo, hi = (0, n_reads) if rows_mode else shard.shard_range(n_reads * world, rank, world)
+    # Weak scaling: rank r classifies global reads [r*n, (r+1)*n) of read set j, and set j starts at global read j*world*n of one
+    # seeded stream (a read's content depends only on (seed, global index): charon_amd/shard.py), so every step of every rank
+    # works on reads no other step or rank has seen.  Row-sharded mode: every rank gets the SAME batch (lo = 0).
     Lmax = max(L, args.read_len_max)
     nseg = 2 if paired else 1   # mates are consecutive synthetic reads 2i, 2i+1 of one read set
-    reads = api.synth_reads(local, 42, genomes, B, wl["genome_len"], (hi - lo) * nseg, L, Lmax, 0.05, 0.10, 40.0, first_read_id=lo * nseg)
-    seg = {}
-    if paired:
-        off = api.device_download(local, reads.seg1_offset, n_reads * 2 * 8, np.uint64)
-        ln = api.device_download(local, reads.seg1_length, n_reads * 2 * 4, np.uint32)
-        for name, arr in (("o1", off[0::2]), ("o2", off[1::2]), ("l1", ln[0::2]), ("l2", ln[1::2])):
-            seg[name] = api.device_malloc(local, arr.nbytes)
-            api.device_upload(local, seg[name], np.ascontiguousarray(arr))
-    stream = api.Stream(index, n_reads, reads.n_bases, profile=True)
+    n_sets = max(1, min(args.read_sets, args.steps + args.warmup))
+    sets = []
+    for j in range(n_sets):
+        lo = j * world * n_reads + (0 if rows_mode else rank * n_reads)
+        rd = api.synth_reads(local, 42, genomes, B, wl["genome_len"], n_reads * nseg, L, Lmax, 0.05, 0.10, 40.0, first_read_id=lo * nseg)
+        seg = {}
+        if paired:
+            off = api.device_download(local, rd.seg1_offset, n_reads * 2 * 8, np.uint64)
+            ln = api.device_download(local, rd.seg1_length, n_reads * 2 * 4, np.uint32)
+            for name, arr in (("o1", off[0::2]), ("o2", off[1::2]), ("l1", ln[0::2]), ("l2", ln[1::2])):
+                seg[name] = api.device_malloc(local, arr.nbytes)
+                api.device_upload(local, seg[name], np.ascontiguousarray(arr))
+        sets.append((rd, seg))
+    max_bases = max(int(rd.n_bases) for rd, _ in sets)
+    stream = api.Stream(index, n_reads, max_bases, profile=True)
     stream.set_model(api.default_model(ncat, 0, paired=paired))
     setup_s = time.time() - t_setup
+    step_no = [0]  # steps submitted so far: step i uses read set i mod n_sets
 
     def submit():
+        reads, seg = sets[step_no[0] % n_sets]
+        step_no[0] += 1
         if paired:
             stream.submit_device(n_reads, reads.n_bases, reads.bases2, seg["o1"], seg["l1"], reads.mean_quality, reads.compression,
                                  seg2_offset=seg["o2"], seg2_length=seg["l2"])
@@ -140,9 +170,11 @@ def main():
                                  reads.compression)
 
     def run_steps_rows(k):
-        """row-sharded chain: minimise (all ranks, same batch) -> probe own rows -> ONE sum all-reduce -> AND/count/call"""
+        """dense row-sharded chain: minimise (all ranks, same batch) -> probe own rows -> ONE sum all-reduce -> AND/count/call"""
         res = None
         for _ in range(k):
+            reads, _ = sets[step_no[0] % n_sets]
+            step_no[0] += 1
             e = stream.shard_minimise_device(n_reads, reads.n_bases, reads.bases2, reads.seg1_offset, reads.seg1_length,
                                              reads.mean_quality, reads.compression)
             nwords = e * 3 * ((B + 63) // 64)
@@ -164,7 +196,7 @@ def main():
     def run_steps(k):
         if rows_mode:
             return run_steps_rows(k)
-        """k whole passes of the chain; two batches in flight so that step i's model+call kernel (side stream) overlaps
+        """k whole passes of the chain; two batches in flight so that step i's count and model+call kernels (side stream) overlap
         step i+1's minimise+probe kernel.  Every step's work starts and ends inside the caller's timed region."""
         res = None
         submit()
@@ -188,6 +220,7 @@ def main():
     res = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    last_reads = sets[(step_no[0] - 1) % n_sets][0]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -203,13 +236,16 @@ def main():
     k2_ms, k2_n = stream.profile(1)
     k3_ms, k3_n = stream.profile(2)
     chain_ms, chain_n = stream.profile(3)
+    _, reruns = stream.profile(4)
     alg_bytes, total_min = stream.last_batch_bytes()
     flags = api.device_download(local, res.flags, n_reads, np.uint8)
 
     pcie_rate = None
-    if args.pcie and world == 1 and not paired and not rows_mode:
+    if not args.no_pcie and world == 1 and not paired and not rows_mode:
         # host-buffer entry: packed batch in PINNED host memory (chn_host_alloc), two batches in flight, so the upload of batch
         # i+1 (copy stream) overlaps the kernels of batch i; results come back into ordinary numpy arrays
+        reads = last_reads
+
         def pinned_copy(dev_ptr, count, dtype):
             a = api.pinned_array(count, dtype)
             a[:] = api.device_download(local, dev_ptr, count * np.dtype(dtype).itemsize, dtype)
@@ -237,7 +273,7 @@ def main():
     out = None
     if rank == 0:
         k1_avg = k1_ms / max(k1_n, 1)
-        traffic = pmc_traffic(args.workload, n_reads, L)
+        traffic = pmc_traffic(args.workload, n_reads, L if Lmax == L else -1)
         achieved = alg_bytes / (k1_avg * 1e-3) / 1e9 if k1_avg > 0 else 0.0
         out = {
             "metric": "classified reads/sec + achieved HBM GB/s vs roofline, 5 kb reads, 39 GB index",
@@ -252,45 +288,122 @@ def main():
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": wl["desc"], "reads_per_step_per_gpu": n_reads, "read_len": L, "read_len_max": Lmax, "bases_per_step_per_gpu": int(reads.n_bases), "index_bytes": S * ((B + 63) // 64) * 8,
+            "config": {"workload": wl["desc"],
+                       "input": "device-resident packed reads (2-bit bases + per-read mean-quality / gzip-ratio columns already in HBM when "
+                                "the timed region starts); host FASTQ parsing, mean quality and the gzip column are excluded",
+                       "timed_region": "length ordering -> minimise+probe -> count -> KDE model + call, %d distinct read set(s) cycled, "
+                                       "two batches in flight" % n_sets,
+                       "reads_per_step_per_gpu": n_reads, "read_len": L, "read_len_max": Lmax, "bases_per_step_per_gpu": int(last_reads.n_bases),
+                       "index_bytes": S * ((B + 63) // 64) * 8,
                        "sharding": ("index rows sharded over ranks, same batch on every rank, one sum all-reduce of probe words per batch" if rows_mode else
                                     "reads sharded over ranks, full index replica per GPU, no data-path collective"),
-                       "mean_minimisers_per_read": total_min / n_reads, "borderline_reads": int(flags.sum()),
+                       "mean_minimisers_per_read": total_min / n_reads, "borderline_reads": int(flags.sum()), "row_log_reruns": int(reruns),
                        "summary_counts": dict([(categories[c], int(summary[c])) for c in range(ncat)] + [("unclassified", int(summary[ncat]))]),
                        "setup_seconds": round(setup_s, 1), "pcie_inclusive_reads_per_s": pcie_rate},
             "roofline": {"bound": "hbm", "kernel": "k_minimise_probe", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic["traffic_bytes"] if traffic else None,
+                         "traffic_source": traffic["source"] if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_avg,
                          "gathers_per_s": (total_min * index.desc.hash_funs / (k1_avg * 1e-3)) if k1_avg > 0 else 0.0,
                          "note": "HBM-bound on random row probes: each probe uses 8*W bytes of a 128-byte line, so traffic/algorithmic ~ 8x is "
                                  "line granularity, not re-reads; the measured pure-gather roof of this chip is 48.6e9 (default policy) to "
                                  "54.3e9 (nt) gathers/s from a 39 GB table (profiles/r01/gather_microbench.txt, gather_policy_microbench.txt)",
                          "other_kernels_avg_ms": {"k_count_wavelog": k2_ms / max(k2_n, 1), "k_model_call": k3_ms / max(k3_n, 1),
-                                                  "whole_chain": chain_ms / max(chain_n, 1)}},
+                                                  "whole_chain": chain_ms / max(chain_n, 1),
+                                                  "note": "count and model+call run on a side stream under the next batch's minimise+probe"}},
         }
+        if rehearsal:
+            out["rehearsal"] = True  # ranks share GPUs / gloo backend: plumbing check only, never a scaling figure
         if world == 1 and not args.no_cpu_baseline and not rows_mode and not paired:
-            out["cpu_baseline"] = cpu_baseline(api, index, reads, res, n_reads, args, local, categories, b2c)
+            out["cpu_baseline"] = cpu_baseline(api, index, last_reads, res, n_reads, args, local, categories, b2c)
     stream.destroy()
     index.destroy()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` from a plain shell: start the N ranks as children (torch.distributed.run, one process per
+    GPU) BEFORE this process touches the GPU, wait for them and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    if args.backend == "nccl" and not args.launch_check:
+        import torch
+        ndev = torch.cuda.device_count()  # does not initialise the GPU in this (parent) process
+        if args.gpus > ndev:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible; RCCL needs one GPU per rank "
+                             "(--backend gloo rehearses the launch on fewer GPUs)" % (args.gpus, ndev))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{"):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line:
+        print(line, flush=True)
+    if rc != 0 or not line:
+        raise SystemExit(rc or 1)
+
+
+def launch_check(args, rank, world, use_dist):
+    """everything bench.py does around the GPU work -- rendezvous, barrier, timed region, MAX over ranks, one JSON line from rank
+    0 -- with a sleep standing in for the steps.  Runs without a GPU (gloo): the CPU test of the --gpus N launch path."""
+    import torch
+    dist = None
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("gloo" if args.backend == "gloo" or torch.cuda.device_count() < world else "nccl")
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1) * args.steps)
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ranks_seen = 1
+    if dist:
+        t = torch.tensor([elapsed, 1.0], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, ranks_seen = float(tmax[0].item()), int(round(float(t[1].item())))
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "rehearsal": True, "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
+                          "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "value": None}), flush=True)
 
 
 def pmc_traffic(workload, n_reads, read_len):
     """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of this same command (FETCH_SIZE and
     WRITE_SIZE in separate passes, gfx950 correction applied; see profiles/rNN/pmc_traffic.json).  bench.py cannot run
-    the profiler on itself, so the most recent committed measurement for the same workload shape is reported."""
+    the profiler on itself, so the most recent committed measurement for the same workload shape is reported, stamped
+    with the commit and date it was taken at so that a stale figure is visible."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
         try:
-            d = json.load(open(f)).get(workload)
+            doc = json.load(open(f))
         except (OSError, ValueError):
             continue
+        d = doc.get(workload)
         if d and d.get("reads_per_launch") == n_reads and d.get("read_len") == read_len:
-            return d["traffic_bytes"]
+            return {"traffic_bytes": d["traffic_bytes"],
+                    "source": "%s (measured at commit %s, %s)" % (os.path.relpath(f, ROOT), doc.get("commit", "unrecorded"), doc.get("date", "undated"))}
     return None
 
 

@@ -16,6 +16,7 @@ _L = C.CDLL(LIB_PATH)
 
 MINIMISER_SEED = 0x8F3F73B5CF1C9ADE
 STREAM_PROFILE = 1
+STREAM_TINY_LOG = 2
 
 
 class IndexDesc(C.Structure):
@@ -224,9 +225,9 @@ def default_model(num_categories, host_index, paired=False, **overrides):
 
 
 class Stream:
-    def __init__(self, index, max_reads, max_bases, profile=False):
+    def __init__(self, index, max_reads, max_bases, profile=False, tiny_log=False):
         self.index = index
-        cfg = StreamCfg(C.sizeof(StreamCfg), STREAM_PROFILE if profile else 0, max_reads, max_bases)
+        cfg = StreamCfg(C.sizeof(StreamCfg), (STREAM_PROFILE if profile else 0) | (STREAM_TINY_LOG if tiny_log else 0), max_reads, max_bases)
         self.h = C.c_void_p()
         _chk(_L.chn_stream_create(index.h, C.byref(cfg), C.byref(self.h)))
         self.C = index.desc.num_categories

@@ -128,6 +128,8 @@ typedef struct chn_stream_cfg {
     uint64_t max_bases;         /* per batch, sum of padded segment lengths */
 } chn_stream_cfg;
 #define CHN_STREAM_PROFILE 1u   /* bracket every kernel with HIP events (chn_stream_profile) */
+#define CHN_STREAM_TINY_LOG 2u  /* testing only: start with a deliberately undersized row log so that every batch takes the
+                                 * overflow -> worst-case re-run path of chn_batch_wait */
 
 int chn_stream_create(chn_index *idx, const chn_stream_cfg *cfg, chn_stream **out);
 int chn_stream_destroy(chn_stream *s);
@@ -160,8 +162,10 @@ typedef struct chn_batch {
 /* Per-read results (what a post-processed + classified ReadEntry holds, include/read_entry.hpp:23-32):
  * num_hashes_, counts_[C], unique_counts_[C], probabilities_[C], call_, confidence_score_.
  * proportions are not returned: they are float(count)/float(num_hashes) (:140-150), recomputed by the caller.
- * `flags` bit 0: the probability comparison that decides `call` was closer than 1e-6 relative, so the host
- * should re-evaluate that read with its own libm (the device exp() may differ from glibc in the last ulp). */
+ * `flags` bit 0: a probability comparison that decides `call` was closer than 2e-6 relative (or a probability sits at the
+ * float underflow edge of the `prob == 0` test of call_category), so the host should re-evaluate that read with its own
+ * libm (the device exp() may differ from glibc in the last ulp).  chn_batch_wait does that itself for host batches with
+ * host result buffers; with on_device results the flags are only reported. */
 typedef struct chn_result {
     uint32_t struct_size;
     uint32_t on_device;        /* 0: pointers below are host buffers to fill; 1: receive device pointers */
@@ -174,9 +178,14 @@ typedef struct chn_result {
     uint8_t *flags;            /* [n] */
 } chn_result;
 
-/* Up to TWO batches may be in flight per stream (submit, submit, wait, submit, wait, ...): batch i's model+call
- * kernel runs on a side HIP stream and overlaps batch i+1's minimise+probe kernel.  chn_batch_wait returns the
- * OLDEST batch in flight.  With on_device results the returned pointers stay valid until the second-next submit. */
+/* Up to TWO batches may be in flight per stream (submit, submit, wait, submit, wait, ...): batch i's count and
+ * model+call kernels run on a side HIP stream and overlap batch i+1's minimise+probe kernel.  chn_batch_wait returns
+ * the OLDEST batch in flight.  With on_device results the returned pointers stay valid until the second-next submit.
+ * Scratch: the per-batch row log is sized for twice the minimiser density of random sequence (not for the worst case
+ * of one minimiser per base); a batch that overruns it is detected on the device and re-run by chn_batch_wait on
+ * worst-case buffers allocated at that point (CHN_E_NOMEM if they do not fit) -- results are identical either way.
+ * A device batch (on_device != 0) whose segments are misaligned or reach beyond n_bases makes chn_batch_wait fail with
+ * CHN_E_INVALID (such segments are never read). */
 int chn_batch_submit(chn_stream *s, const chn_batch *b);   /* asynchronous */
 int chn_batch_wait(chn_stream *s, chn_result *r);          /* blocks; fills / points `r` */
 int chn_stream_sync(chn_stream *s);
@@ -214,7 +223,8 @@ int chn_minimisers(chn_stream *s, const chn_batch *b, uint64_t *host_values, uin
 int chn_index_emplace(chn_index *idx, const uint64_t *host_values, uint64_t n_values, uint32_t bin);
 
 /* Per-kernel device time accumulated since the last reset (CHN_STREAM_PROFILE streams only).
- * which: 0 = minimise+probe kernel, 1 = count kernel, 2 = model+call kernel, 3 = whole batch chain. */
+ * which: 0 = minimise+probe kernel, 1 = count kernel, 2 = model+call kernel, 3 = whole batch chain;
+ * 4 (any stream): *launches = number of batches chn_batch_wait re-ran on worst-case buffers after a row-log overflow. */
 int chn_stream_profile(chn_stream *s, int which, double *total_ms, uint64_t *launches, int reset);
 /* Algorithmic bytes of the last batch by SURVEY 8(d): sum over reads of ceil(L/4) + M*h*W*8 + (8 + 8C). */
 int chn_stream_last_batch_bytes(chn_stream *s, uint64_t *bytes, uint64_t *total_minimisers);

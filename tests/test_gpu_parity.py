@@ -511,3 +511,115 @@ def test_two_streams_driven_from_two_host_threads(api, oracle_lib):
     g.destroy()
     oidx.free()
     assert not errors, errors
+
+
+def test_row_log_overflow_reruns_on_worst_case_buffers(api, oracle_lib):
+    """the row log is sized for twice the minimiser density of random sequence; a batch that overruns it is detected on the
+    device and re-run by chn_batch_wait on worst-case buffers.  CHN_STREAM_TINY_LOG forces that path; results must not change."""
+    from charon_amd import pack
+    r = util.rng(55)
+    gs = [util.random_seq(r, 3000) for _ in range(70)]
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [i % 2 for i in range(70)], ["human", "microbial"], bin_size=9001,
+                                   fill_seed=8, fill=0.25)  # W = 2, heavy fill: many escaped rows as well
+    reads = util.sample_reads(r, gs, 500, (50, 2500), sub_rate=0.03) + [b"A" * 900, b"", b"ACGT" * 200]
+    orc = run_oracle(oidx, reads)
+    g = util.gpu_index_from_oracle(api, oidx)
+    p = pack.pack_reads(reads)
+    n = len(reads)
+    for tiny, two in ((True, False), (True, True), (False, True)):
+        st = api.Stream(g, n, p["n_bases"], tiny_log=tiny)
+        st.set_model(api.default_model(2, 0))
+        mq, cp = np.full(n, 40.0, np.float32), np.zeros(n, np.float32)
+        st.submit_host(p, mq, cp)
+        if two:
+            st.submit_host(p, mq, cp)
+        outs = [st.wait_host() for _ in range(2 if two else 1)]
+        for o in outs:
+            util.assert_parity(o, orc)
+        assert st.profile(4)[1] == (len(outs) if tiny else 0)
+        st.destroy()
+    g.destroy()
+    oidx.free()
+
+
+def test_device_batches_bad_and_overlapping_segments(api, oracle_lib):
+    """device batches are not validated by the host: a segment reaching beyond n_bases (or misaligned) must never be read and
+    makes chn_batch_wait fail; overlapping segments (chunked references) whose lengths add up to more than n_bases are fine."""
+    from charon_amd import pack
+    r = util.rng(56)
+    gs = [util.random_seq(r, 6000) for _ in range(3)]
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [0, 1, 1], ["host", "microbial"], bin_size=20011)
+    g = util.gpu_index_from_oracle(api, oidx)
+    p = pack.pack_reads([gs[0]])  # one 6 000-base sequence; segments below are windows into it
+    nb = p["n_bases"]
+    d_bases = api.device_malloc(0, nb // 4)
+    api.device_upload(0, d_bases, p["bases2"])
+    offs = np.arange(0, 5760, 64, dtype=np.uint64)          # 90 windows, 64 bases apart ...
+    lens = np.minimum(2000, 6000 - offs).astype(np.uint32)  # ... of up to 2 000 bases: sum of lengths >> n_bases
+    assert int(lens.sum()) > 10 * nb
+    d_off, d_len = api.device_malloc(0, offs.nbytes), api.device_malloc(0, lens.nbytes)
+    api.device_upload(0, d_off, offs)
+    api.device_upload(0, d_len, lens)
+    n = len(offs)
+    st = api.Stream(g, n, nb)
+    st.set_model(api.default_model(2, 0))
+    st.submit_device(n, nb, d_bases, d_off, d_len)
+    gpu = util.download_results(api, st.wait_device(), n, 2)
+    windows = [gs[0][int(o):int(o) + int(l)] for o, l in zip(offs, lens)]
+    seqs, so, _ = util.concat(windows)
+    orc = oidx.process_reads(seqs, so, mq_const=0.0)
+    util.assert_parity(gpu, orc)
+    # now break two segments: one reaches beyond the buffer, one is misaligned
+    for bad_off, bad_len in ((offs[5], nb), (offs[7] + 3, 100)):
+        o2, l2 = offs.copy(), lens.copy()
+        o2[5 if bad_len == nb else 7] = bad_off
+        l2[5 if bad_len == nb else 7] = bad_len
+        api.device_upload(0, d_off, o2)
+        api.device_upload(0, d_len, l2)
+        st.submit_device(n, nb, d_bases, d_off, d_len)
+        with pytest.raises(api.ChnError, match="misaligned or lies outside"):
+            st.wait_device()
+    # the stream stays usable
+    api.device_upload(0, d_off, offs)
+    api.device_upload(0, d_len, lens)
+    st.submit_device(n, nb, d_bases, d_off, d_len)
+    util.assert_parity(util.download_results(api, st.wait_device(), n, 2), orc)
+    st.destroy()
+    for ptr in (d_bases, d_off, d_len):
+        api.device_free(0, ptr)
+    g.destroy()
+    oidx.free()
+
+
+def test_borderline_reads_are_flagged_and_reevaluated_on_the_host(api, oracle_lib):
+    """reads whose deciding probability comparison is a tie (both categories equally likely) carry flags != 0 and are
+    re-evaluated by chn_batch_wait with the host libm (host_model_call); the result must equal the oracle's"""
+    r = util.rng(57)
+    gs = [util.random_seq(r, 5000) for _ in range(4)]
+    # single-end: confidence threshold 0 opens the gate for reads without any unique hit (hp == op exactly)
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs[:2]], [0, 1], ["host", "microbial"])
+    reads = util.sample_reads(r, gs[:2], 150, (150, 900), sub_rate=0.05, random_fraction=0.4)
+    g = util.gpu_index_from_oracle(api, oidx)
+    thr = oracle_lib.default_thresholds()
+    thr.confidence_threshold = 0
+    seqs, offs, _ = util.concat(reads)
+    orc = oidx.process_reads(seqs, offs, thr=thr)
+    gpu = run_gpu(api, g, reads, comp=0.0, model=api.default_model(2, 0, confidence_threshold=0))
+    assert gpu["flags"].sum() > 10
+    util.assert_parity(gpu, orc)
+    g.destroy()
+    oidx.free()
+    # paired (call_category): --confidence 255 narrows to -1 (int8), so `conf > threshold` always holds and pf > ps decides
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [0, 1, 2, 3], ["host", "a", "b", "c"])
+    m1 = util.sample_reads(r, gs, 150, 150, sub_rate=0.02, random_fraction=0.4)
+    m2 = util.sample_reads(r, gs, 150, 150, sub_rate=0.02, random_fraction=0.4)
+    g = util.gpu_index_from_oracle(api, oidx)
+    thr = oracle_lib.default_thresholds(paired=True)
+    thr.confidence_threshold = 255
+    seqs, offs, split = util.concat(m1, m2)
+    orc = oidx.process_reads(seqs, offs, mate_split=split, thr=thr)
+    gpu = run_gpu(api, g, m1, m2, comp=0.0, model=api.default_model(4, 0, paired=True, confidence_threshold=-1))
+    assert gpu["flags"].sum() > 10
+    util.assert_parity(gpu, orc)
+    g.destroy()
+    oidx.free()

@@ -99,3 +99,26 @@ def test_row_sharded_probe_words_sum_reconstructs(oracle_lib):
         a, b = np.load(os.path.join(d, "s0.npy")), np.load(os.path.join(d, "s1.npy"))
     assert a[0] == 1 and b[0] == 1
     assert (a[1], a[2], b[1], b[2]) == (0, 2502, 2502, 5003)
+
+
+def test_bench_launches_its_own_ranks_from_a_plain_shell():
+    """`python bench.py --gpus 2` without torch.distributed.run around it must start the two ranks itself (before touching the
+    GPU), rendezvous on 127.0.0.1, reduce the timing with MAX over ranks and relay exactly one JSON line from rank 0.  There is
+    no GPU here, so the steps are rehearsed (--launch-check); the launch, rendezvous and reduction code is the real one."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--launch-check", "--steps", "2"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["rehearsal"] is True and out["launch_check"] is True
+    # rank 1 sleeps twice as long as rank 0: the reported time is the MAX over ranks
+    assert out["ms_per_step"] >= 19.0
+    # more ranks than GPUs on the RCCL backend is refused outright (no GPU here -> any N > 0 is too many)
+    p = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert p.returncode != 0 and "RCCL needs one GPU per rank" in (p.stderr + p.stdout)

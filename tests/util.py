@@ -101,3 +101,23 @@ def assert_parity(gpu, orc, prob_tol=1e-6):
     assert np.array_equal(np.isnan(a), np.isnan(b))
     ok = ~np.isnan(a)
     assert np.max(np.abs(a[ok] - b[ok]), initial=0.0) <= prob_tol
+
+
+def download_results(api, res, n, ncat, device=0):
+    """device-resident chn_result -> the dict layout of Stream.wait_host()"""
+    return dict(num_hashes=api.device_download(device, res.num_hashes, n * 4, np.uint32),
+                counts=api.device_download(device, res.counts, n * ncat * 4, np.uint32).reshape(n, ncat),
+                unique=api.device_download(device, res.unique_counts, n * ncat * 4, np.uint32).reshape(n, ncat),
+                probs=api.device_download(device, res.probabilities, n * ncat * 8, np.float64).reshape(n, ncat),
+                call=api.device_download(device, res.call, n, np.uint8), conf=api.device_download(device, res.confidence, n, np.uint8),
+                flags=api.device_download(device, res.flags, n, np.uint8))
+
+
+def free_synth_reads(api, rd, device=0):
+    for p in (rd.bases2, rd.seg1_offset, rd.seg1_length, rd.mean_quality, rd.compression):
+        api.device_free(device, p)
+
+
+def assert_same_results(a, b, keys=("num_hashes", "counts", "unique", "call", "conf", "probs")):
+    for key in keys:
+        assert np.array_equal(a[key], b[key], equal_nan=True) if key == "probs" else np.array_equal(a[key], b[key]), key
