@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcharon_hip.so")
+LIB_PATH = os.environ.get("CHARON_HIP_LIB") or os.path.join(HERE, "libcharon_hip.so")  # the override is for A/B diagnostics builds
 if not os.path.exists(LIB_PATH):
     raise ImportError("charon_amd: %s not built -- run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
 _L = C.CDLL(LIB_PATH)

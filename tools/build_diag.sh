@@ -1,0 +1,23 @@
+#!/bin/bash
+# Diagnostics builds of libcharon_hip.so for A/B experiments (never shipped, never loaded by default):
+#   tools/diag/libcharon_hip_fake_emit.so   -DCHN_K1_FAKE_EMIT: k_minimise_probe without hashing (probe pipeline alone)
+# Use with CHARON_HIP_LIB=<path> python bench.py ...
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+mkdir -p $R/tools/diag
+for v in "$@"; do
+  case $v in
+    fake_emit) D="-DCHN_K1_FAKE_EMIT" ;;
+    fake_nostore) D="-DCHN_K1_FAKE_EMIT -DCHN_DIAG_NO_STORE" ;;
+    fake_nobase) D="-DCHN_K1_FAKE_EMIT -DCHN_DIAG_NO_BASE" ;;
+    fake_nostore_nobase) D="-DCHN_K1_FAKE_EMIT -DCHN_DIAG_NO_STORE -DCHN_DIAG_NO_BASE" ;;
+    nostore) D="-DCHN_DIAG_NO_STORE" ;;
+    pieces1) D="-DCHN_BASE_PIECES=1" ;;
+    pieces2) D="-DCHN_BASE_PIECES=2" ;;
+    pieces4) D="-DCHN_BASE_PIECES=4" ;;
+    pieces8) D="-DCHN_BASE_PIECES=8" ;;
+    *) D="-D$v" ;;
+  esac
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++14 -ffp-contract=off -fPIC -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-but-set-variable -I$R/include -I$R/charon_amd/csrc $D -shared \
+      -o $R/tools/diag/libcharon_hip_$v.so $R/charon_amd/csrc/charon_hip.hip
+done
