@@ -12,6 +12,10 @@ for v in "$@"; do
     fake_nobase) D="-DCHN_K1_FAKE_EMIT -DCHN_DIAG_NO_BASE" ;;
     fake_nostore_nobase) D="-DCHN_K1_FAKE_EMIT -DCHN_DIAG_NO_STORE -DCHN_DIAG_NO_BASE" ;;
     nostore) D="-DCHN_DIAG_NO_STORE" ;;
+    batch1) D="-DCHN_LOG_BATCH=1" ;;
+    batch8) D="-DCHN_LOG_BATCH=8" ;;
+    batch4_pieces8) D="-DCHN_LOG_BATCH=4 -DCHN_BASE_PIECES=8" ;;
+    fake_batch4) D="-DCHN_K1_FAKE_EMIT -DCHN_LOG_BATCH=4" ;;
     pieces1) D="-DCHN_BASE_PIECES=1" ;;
     pieces2) D="-DCHN_BASE_PIECES=2" ;;
     pieces4) D="-DCHN_BASE_PIECES=4" ;;
