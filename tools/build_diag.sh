@@ -1,6 +1,9 @@
 #!/bin/bash
 # Diagnostics builds of libcharon_hip.so for A/B experiments (never shipped, never loaded by default):
 #   tools/diag/libcharon_hip_fake_emit.so   -DCHN_K1_FAKE_EMIT: k_minimise_probe without hashing (probe pipeline alone)
+# (CHN_DIAG_NO_STORE / CHN_DIAG_NO_ESC_STORE builds are NOT offered here any more: they leave the row log unwritten, and the
+#  count kernel then chases garbage escaped-row indices -- a GPU memory fault; they were only ever meaningful with the
+#  count kernel's output ignored.)
 # Use with CHARON_HIP_LIB=<path> python bench.py ...
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
@@ -8,10 +11,8 @@ mkdir -p $R/tools/diag
 for v in "$@"; do
   case $v in
     fake_emit) D="-DCHN_K1_FAKE_EMIT" ;;
-    fake_nostore) D="-DCHN_K1_FAKE_EMIT -DCHN_DIAG_NO_STORE" ;;
     fake_nobase) D="-DCHN_K1_FAKE_EMIT -DCHN_DIAG_NO_BASE" ;;
-    fake_nostore_nobase) D="-DCHN_K1_FAKE_EMIT -DCHN_DIAG_NO_STORE -DCHN_DIAG_NO_BASE" ;;
-    nostore) D="-DCHN_DIAG_NO_STORE" ;;
+    nofast) D="-DCHN_K1_NO_FAST_STEP" ;;
     batch1) D="-DCHN_LOG_BATCH=1" ;;
     batch8) D="-DCHN_LOG_BATCH=8" ;;
     batch4_pieces8) D="-DCHN_LOG_BATCH=4 -DCHN_BASE_PIECES=8" ;;
