@@ -65,10 +65,11 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; nccl = RCCL (default). gloo only to rehearse N ranks on fewer GPUs")
-    ap.add_argument("--shard", default="reads", choices=["reads", "rows"],
+    ap.add_argument("--shard", default="reads", choices=["reads", "rows", "rows-dense"],
                     help="reads (default): full index replica per rank, reads sharded, no data-path collective; "
-                         "rows: index row-range sharded over ranks, every rank minimises the same batch, one RCCL sum "
-                         "all-reduce of the probe words per batch (for indexes that do not fit one GPU)")
+                         "rows: index row-range sharded over ranks (for indexes that do not fit one GPU), every rank classifies its own "
+                         "reads and exchanges row queries / row words with the owners (two all-to-alls per batch); "
+                         "rows-dense: the older scheme, every rank minimises the same batch, one RCCL sum all-reduce of all probe words")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer leg (H2D of the packed batch + D2H of the results)")
     ap.add_argument("--read-sets", type=int, default=3, help="distinct synthetic read sets the steps cycle through")
     ap.add_argument("--launch-check", action="store_true",
@@ -125,8 +126,9 @@ def main():
     ncat = len(categories)
 
     t_setup = time.time()
-    rows_mode = args.shard == "rows"
-    if rows_mode:
+    rows_mode = args.shard == "rows-dense"   # every rank works on the SAME batch
+    sparse_mode = args.shard == "rows"      # every rank works on its own reads, rows are fetched from their owners
+    if rows_mode or sparse_mode:
         rlo, rhi = shard.shard_range(S, rank, world)
         desc = api.make_desc(B, S, b2c, ncat, 0, device=local, row_begin=rlo, row_end=rhi)
     else:
@@ -156,6 +158,10 @@ def main():
     max_bases = max(int(rd.n_bases) for rd, _ in sets)
     stream = api.Stream(index, n_reads, max_bases, profile=True)
     stream.set_model(api.default_model(ncat, 0, paired=paired))
+    stream_b = None
+    if sparse_mode:  # a second stream: batch i+1 is minimised while batch i's rows are fetched
+        stream_b = api.Stream(index, n_reads, max_bases, profile=True)
+        stream_b.set_model(api.default_model(ncat, 0, paired=paired))
     setup_s = time.time() - t_setup
     step_no = [0]  # steps submitted so far: step i uses read set i mod n_sets
 
@@ -193,9 +199,69 @@ def main():
             del partial
         return res
 
+    splits = shard.row_splits(S, world)
+    Wd = (B + 63) // 64
+    xbuf = {}  # per stream: torch buffers of the exchange, grown on demand
+
+    def xtensor(key, count, dtype):
+        t = xbuf.get(key)
+        if t is None or t.numel() < count:
+            t = torch.empty(int(count * 1.1) + 1024, dtype=dtype, device=torch.device("cuda", local))
+            xbuf[key] = t
+        return t
+
+    def sparse_minimise(st):
+        reads, _ = sets[step_no[0] % n_sets]
+        step_no[0] += 1
+        st.shardx_minimise_device(n_reads, reads.n_bases, reads.bases2, reads.seg1_offset, reads.seg1_length, reads.mean_quality, reads.compression)
+
+    def sparse_rest(st, tag):
+        """queries -> (all-to-all) -> serve -> (all-to-all back) -> AND / count / call"""
+        n_probes, counts = st.shardx_counts(splits)
+        q = xtensor((tag, "q"), n_probes, torch.int32)
+        st.shardx_queries(q.data_ptr(), q.numel())
+        if use_dist and world > 1:
+            st.sync()
+            if args.backend == "nccl":
+                qin, rc = shard.all_to_all_v(dist, q[:n_probes], counts)
+            else:  # gloo rehearsal: through host memory
+                qh, rc = shard.all_to_all_v(dist, q[:n_probes].cpu(), counts)
+                qin = qh.to(q.device)
+            n_in = sum(rc)
+            torch.cuda.synchronize()
+        else:
+            qin, n_in, rc = q, n_probes, counts
+        rows = xtensor((tag, "rows"), n_in * Wd, torch.int64)
+        st.shardx_serve(index, qin.data_ptr(), n_in, rows.data_ptr())
+        if use_dist and world > 1:
+            st.sync()
+            if args.backend == "nccl":
+                back, _ = shard.all_to_all_v(dist, rows[:n_in * Wd], rc, width=Wd)
+            else:
+                bh, _ = shard.all_to_all_v(dist, rows[:n_in * Wd].cpu(), rc, width=Wd)
+                back = bh.to(q.device)
+            torch.cuda.synchronize()
+            xbuf[(tag, "back")] = back  # keep alive until the batch is waited for
+        else:
+            back = rows
+        st.shardx_finish(back.data_ptr())
+
+    def run_steps_sparse(k):
+        sts = [stream, stream_b]
+        res = None
+        sparse_minimise(sts[0])
+        for i in range(k):
+            if i + 1 < k:
+                sparse_minimise(sts[(i + 1) % 2])  # queued before this batch's row fetches: the two overlap on the device
+            sparse_rest(sts[i % 2], i % 2)
+            res = sts[i % 2].wait_device()
+        return res
+
     def run_steps(k):
         if rows_mode:
             return run_steps_rows(k)
+        if sparse_mode:
+            return run_steps_sparse(k)
         """k whole passes of the chain; two batches in flight so that step i's count and model+call kernels (side stream) overlap
         step i+1's minimise+probe kernel.  Every step's work starts and ends inside the caller's timed region."""
         res = None
@@ -241,7 +307,7 @@ def main():
     flags = api.device_download(local, res.flags, n_reads, np.uint8)
 
     pcie_rate = None
-    if not args.no_pcie and world == 1 and not paired and not rows_mode:
+    if not args.no_pcie and world == 1 and not paired and not rows_mode and not sparse_mode:
         # host-buffer entry: packed batch in PINNED host memory (chn_host_alloc), two batches in flight, so the upload of batch
         # i+1 (copy stream) overlaps the kernels of batch i; results come back into ordinary numpy arrays
         reads = last_reads
@@ -296,6 +362,7 @@ def main():
                        "reads_per_step_per_gpu": n_reads, "read_len": L, "read_len_max": Lmax, "bases_per_step_per_gpu": int(last_reads.n_bases),
                        "index_bytes": S * ((B + 63) // 64) * 8,
                        "sharding": ("index rows sharded over ranks, same batch on every rank, one sum all-reduce of probe words per batch" if rows_mode else
+                                    "index rows AND reads sharded over ranks; per batch one all-to-all of 4-byte row queries and one of the row words back" if sparse_mode else
                                     "reads sharded over ranks, full index replica per GPU, no data-path collective"),
                        "mean_minimisers_per_read": total_min / n_reads, "borderline_reads": int(flags.sum()), "row_log_reruns": int(reruns),
                        "summary_counts": dict([(categories[c], int(summary[c])) for c in range(ncat)] + [("unclassified", int(summary[ncat]))]),
@@ -314,9 +381,11 @@ def main():
         }
         if rehearsal:
             out["rehearsal"] = True  # ranks share GPUs / gloo backend: plumbing check only, never a scaling figure
-        if world == 1 and not args.no_cpu_baseline and not rows_mode and not paired:
+        if world == 1 and not args.no_cpu_baseline and not rows_mode and not sparse_mode and not paired:
             out["cpu_baseline"] = cpu_baseline(api, index, last_reads, res, n_reads, args, local, categories, b2c)
     stream.destroy()
+    if stream_b is not None:
+        stream_b.destroy()
     index.destroy()
     if use_dist:
         dist.barrier()

@@ -65,7 +65,7 @@ EXPORTS = ["chn_index_create", "chn_index_upload_rows", "chn_index_device_words"
            "chn_model_set", "chn_batch_submit", "chn_batch_wait", "chn_stream_sync", "chn_classify_counts", "chn_stream_profile",
            "chn_stream_last_batch_bytes", "chn_synth_genomes", "chn_synth_fill_index", "chn_synth_plant", "chn_synth_reads",
            "chn_device_free", "chn_device_download", "chn_device_malloc", "chn_device_upload", "chn_host_alloc", "chn_host_free", "chn_shard_minimise",
-           "chn_shard_probe", "chn_shard_finish", "chn_minimisers", "chn_index_emplace", "chn_index_decode_ef", "chn_index_bin_popcounts", "chn_last_error", "chn_version"]
+           "chn_shard_probe", "chn_shard_finish", "chn_shardx_minimise", "chn_shardx_counts", "chn_shardx_queries", "chn_shardx_serve", "chn_shardx_finish", "chn_minimisers", "chn_index_emplace", "chn_index_decode_ef", "chn_index_bin_popcounts", "chn_last_error", "chn_version"]
 
 _L.chn_last_error.restype = C.c_char_p
 _L.chn_version.restype = C.c_char_p
@@ -98,6 +98,11 @@ _L.chn_device_upload.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
 _L.chn_shard_minimise.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(C.c_uint64)]
 _L.chn_shard_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
 _L.chn_shard_finish.argtypes = [C.c_void_p, C.c_void_p]
+_L.chn_shardx_minimise.argtypes = [C.c_void_p, C.POINTER(Batch)]
+_L.chn_shardx_counts.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+_L.chn_shardx_queries.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+_L.chn_shardx_serve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+_L.chn_shardx_finish.argtypes = [C.c_void_p, C.c_void_p]
 _L.chn_minimisers.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
 _L.chn_index_emplace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
 _L.chn_index_decode_ef.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64,
@@ -296,6 +301,38 @@ class Stream:
 
     def shard_finish(self, dev_partial):
         _chk(_L.chn_shard_finish(self.h, dev_partial))
+        self._fifo.append(self._shard)
+        self._shard = None
+
+    # ---- row-sharded mode, sparse exchange (see include/charon_hip.h) ----
+    def shardx_minimise_host(self, packed, mean_quality=None, compression=None):
+        b, keep, n = self._host_batch(packed, mean_quality, compression)
+        _chk(_L.chn_shardx_minimise(self.h, C.byref(b)))
+        self._shard = (n, keep)
+
+    def shardx_minimise_device(self, n_reads, n_bases, bases2, seg1_offset, seg1_length, mean_quality=None, compression=None):
+        b = Batch()
+        b.struct_size, b.on_device, b.n_reads, b.n_bases = C.sizeof(Batch), 1, n_reads, n_bases
+        b.bases2, b.seg1_offset, b.seg1_length, b.mean_quality, b.compression = bases2, seg1_offset, seg1_length, mean_quality, compression
+        _chk(_L.chn_shardx_minimise(self.h, C.byref(b)))
+        self._shard = (n_reads, None)
+
+    def shardx_counts(self, row_splits):
+        sp = np.ascontiguousarray(row_splits, dtype=np.uint64)
+        n_ranks = sp.size - 1
+        counts = np.zeros(n_ranks, np.uint64)
+        total = C.c_uint64()
+        _chk(_L.chn_shardx_counts(self.h, n_ranks, sp.ctypes.data, C.byref(total), counts.ctypes.data))
+        return total.value, [int(x) for x in counts]
+
+    def shardx_queries(self, dev_queries, capacity):
+        _chk(_L.chn_shardx_queries(self.h, dev_queries, capacity))
+
+    def shardx_serve(self, shard_index, dev_queries_in, n_in, dev_rows_out):
+        _chk(_L.chn_shardx_serve(self.h, shard_index.h, dev_queries_in, n_in, dev_rows_out))
+
+    def shardx_finish(self, dev_rows_back):
+        _chk(_L.chn_shardx_finish(self.h, dev_rows_back))
         self._fifo.append(self._shard)
         self._shard = None
 

@@ -42,6 +42,7 @@
 #include "parts/k1_minimise_probe.inc"
 #include "parts/k2_count_wavelog.inc"
 #include "parts/shard_kernels.inc"
+#include "parts/shardx_kernels.inc"
 #include "parts/k3_model_call.inc"
 #include "parts/len_order.inc"
 #include "parts/ef_decode.inc"
@@ -49,4 +50,5 @@
 #include "parts/abi_index_model.inc"
 #include "parts/abi_stream_batch.inc"
 #include "parts/abi_shard_wait.inc"
+#include "parts/abi_shardx.inc"
 #include "parts/abi_synth_memory.inc"

@@ -198,7 +198,7 @@ int chn_classify_counts(chn_stream *s, uint64_t n_reads, const uint32_t *num_has
                         const uint32_t *unique_counts, const uint32_t *lengths, const float *mean_quality,
                         const float *compression, double *probabilities, uint8_t *call, uint8_t *confidence);
 
-/* ---- row-sharded ("hash-bin" sharded) mode ---------------------------------------------------------------
+/* ---- row-sharded ("hash-bin" sharded) mode, dense exchange (the checker of the sparse exchange below) -----------
  * For an index too large for one GPU: rank r creates a chn_index with row_begin/row_end = its slice and a stream on it.
  * Per batch, on EVERY rank and for the SAME batch:
  *   1. chn_shard_minimise   all reads are minimised (redundantly); returns E = number of minimisers of the batch
@@ -211,6 +211,30 @@ int chn_classify_counts(chn_stream *s, uint64_t n_reads, const uint32_t *num_has
 int chn_shard_minimise(chn_stream *s, const chn_batch *b, uint64_t *n_entries);
 int chn_shard_probe(chn_stream *s, const chn_index *shard, uint64_t *dev_partial, uint64_t capacity_words);
 int chn_shard_finish(chn_stream *s, const uint64_t *dev_partial);
+
+/* ---- row-sharded mode, sparse exchange -----------------------------------------------------------------------
+ * The faster way to use an index whose rows are spread over n_ranks GPUs (rank r holds rows [row_splits[r], row_splits[r+1])):
+ * every rank classifies ITS OWN reads, asks the owners for the rows it needs and gets them back.  Per batch, on every rank:
+ *   1. chn_shardx_minimise   (asynchronous) the rank's reads are minimised; nothing is probed yet
+ *   2. chn_shardx_counts     (blocks) send_counts[r] = number of probes (minimiser x hash function) whose row rank r owns,
+ *                            *n_probes = their sum
+ *   3. chn_shardx_queries    (asynchronous) dev_queries[n_probes]: the owner-local row number of every probe, grouped by owner
+ *                            rank in rank order
+ *   4. the caller exchanges the groups (all-to-all, 4 bytes per probe; RCCL on torch tensors -- the library has no RCCL dependency)
+ *   5. chn_shardx_serve      (asynchronous; on the OWNER) dev_rows_out[j][w] = word w of the shard's row dev_queries_in[j]
+ *   6. the caller sends the rows back the way the queries came (second all-to-all, 8 * bin_words bytes per probe), so that
+ *      dev_rows_back is laid out exactly like dev_queries
+ *   7. chn_shardx_finish     (asynchronous) AND over the h hash functions, counts, model+call; then chn_batch_wait as usual.
+ * The asynchronous calls run on the stream's HIP stream: call chn_stream_sync before handing a buffer to a collective that runs
+ * on another stream.  The stream `s` may be created on any index object of the same IBF (its rows are not read by steps 1-4, 7);
+ * one sharded batch at a time per stream (use two streams to overlap step 1 of the next batch with step 5 of this one).
+ * No reference counterpart (the reference is single-process); replaces the same loop body as chn_batch_submit. */
+int chn_shardx_minimise(chn_stream *s, const chn_batch *b);
+int chn_shardx_counts(chn_stream *s, uint32_t n_ranks, const uint64_t *row_splits /* [n_ranks + 1] */, uint64_t *n_probes,
+                      uint64_t *send_counts /* [n_ranks] */);
+int chn_shardx_queries(chn_stream *s, uint32_t *dev_queries, uint64_t capacity);
+int chn_shardx_serve(chn_stream *s, const chn_index *shard, const uint32_t *dev_queries_in, uint64_t n_in, uint64_t *dev_rows_out);
+int chn_shardx_finish(chn_stream *s, const uint64_t *dev_rows_back);
 
 /* ---- index construction (`charon index`, src/index_main.cpp:118-160,238-263) ------------------------------
  * chn_minimisers: all minimisers emitted for the segments of `b` (seqan3 minimiser_hash with the stream's k, w), with

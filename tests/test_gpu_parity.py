@@ -623,3 +623,76 @@ def test_borderline_reads_are_flagged_and_reevaluated_on_the_host(api, oracle_li
     util.assert_parity(gpu, orc)
     g.destroy()
     oidx.free()
+
+
+def test_sparse_row_sharded_exchange_equals_replica_mode(api, oracle_lib):
+    """north-star config 4, sparse form, rehearsed on one GPU: the index rows are split over three shards (uneven, one of them
+    tiny), two 'ranks' each classify THEIR OWN half of the reads: minimise -> per-owner query groups -> (host-side stand-in for
+    the all-to-all) -> every owner serves its rows -> rows travel back in query order -> AND / count / call.  Must equal the
+    oracle (and hence the whole-index path) bit for bit, for the fused-shaped (W = 1) and the general (W = 2) index."""
+    from charon_amd import pack
+    r = util.rng(41)
+    for B, cats in ((2, [0, 1]), (70, [i % 2 for i in range(70)])):
+        gs = [util.random_seq(r, 2500) for _ in range(B)]
+        oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], cats, ["host", "microbial"], bin_size=30011, fill_seed=3, fill=0.05)
+        reads = util.sample_reads(r, gs, 400, (50, 2000), sub_rate=0.03) + [b"A" * 300, b"", b"ACGT" * 40]
+        S, Wd = oidx.bin_size, oidx.bin_words
+        splits = [0, 17, S // 3, S]           # three owners
+        words = oidx.words()
+        shards = []
+        for lo, hi in zip(splits[:-1], splits[1:]):
+            sh = api.Index(api.make_desc(oidx.bins, S, oidx.bin_to_cat, 2, 0, row_begin=lo, row_end=hi))
+            sh.upload(words[lo * Wd:hi * Wd], row_begin=lo)
+            shards.append(sh)
+        n_own = len(shards)
+        halves = [reads[:len(reads) // 2], reads[len(reads) // 2:]]
+        ranks = []
+        for k, mine in enumerate(halves):     # a "rank" = a stream (on any shard object of the IBF) + its own reads
+            p = pack.pack_reads(mine)
+            st = api.Stream(shards[k], len(mine), p["n_bases"])
+            st.set_model(api.default_model(2, 0))
+            st.shardx_minimise_host(p, np.full(len(mine), 40.0, np.float32), np.zeros(len(mine), np.float32))
+            n_probes, counts = st.shardx_counts(splits)
+            assert n_probes == sum(counts)
+            dq = api.device_malloc(0, max(n_probes, 1) * 4)
+            st.shardx_queries(dq, n_probes)
+            st.sync()
+            q = api.device_download(0, dq, n_probes * 4, np.uint32)
+            ranks.append(dict(st=st, n=len(mine), n_probes=n_probes, counts=counts, q=q, dq=dq, mine=mine))
+        # the "all-to-all": owner o receives, from every rank in rank order, that rank's group o
+        back = [np.zeros((rk["n_probes"], Wd), np.uint64) for rk in ranks]
+        for o, sh in enumerate(shards):
+            groups = [rk["q"][sum(rk["counts"][:o]):sum(rk["counts"][:o + 1])] for rk in ranks]
+            qin = np.concatenate(groups)
+            assert (qin < splits[o + 1] - splits[o]).all()
+            d_in, d_out = api.device_malloc(0, max(qin.size, 1) * 4), api.device_malloc(0, max(qin.size, 1) * Wd * 8)
+            api.device_upload(0, d_in, qin)
+            ranks[0]["st"].shardx_serve(sh, d_in, qin.size, d_out)   # any stream on the owner's device serves
+            ranks[0]["st"].sync()
+            rows = api.device_download(0, d_out, qin.size * Wd * 8, np.uint64).reshape(-1, Wd)
+            assert np.array_equal(rows, words.reshape(-1, Wd)[splits[o] + qin.astype(np.int64)])
+            at = 0
+            for rk, grp, bk in zip(ranks, groups, back):   # ... and sends every rank's rows back, in the order they came
+                lo = sum(rk["counts"][:o])
+                bk[lo:lo + grp.size] = rows[at:at + grp.size]
+                at += grp.size
+            api.device_free(0, d_in)
+            api.device_free(0, d_out)
+        seen = 0
+        for rk, bk in zip(ranks, back):
+            d_back = api.device_malloc(0, max(bk.size, 1) * 8)
+            api.device_upload(0, d_back, bk)
+            rk["st"].shardx_finish(d_back)
+            gpu = rk["st"].wait_host()
+            seqs, offs, _ = util.concat(rk["mine"])
+            orc = oidx.process_reads(seqs, offs)
+            util.assert_parity(gpu, orc)
+            assert rk["n_probes"] == int(orc["num_hashes"].sum()) * 3
+            seen += rk["n"]
+            api.device_free(0, d_back)
+            api.device_free(0, rk["dq"])
+            rk["st"].destroy()
+        assert seen == len(reads)
+        for sh in shards:
+            sh.destroy()
+        oidx.free()

@@ -122,3 +122,47 @@ def test_bench_launches_its_own_ranks_from_a_plain_shell():
     p = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
                        timeout=300, env=env)
     assert p.returncode != 0 and "RCCL needs one GPU per rank" in (p.stderr + p.stdout)
+
+
+def _sparse_worker(rank, world, initfile, outdir):
+    """sparse row-sharded exchange on CPU: each rank owns a row range AND its own minimisers; queries grouped by owner go out
+    through shard.all_to_all_v, the owner gathers its rows, the rows come back through the reverse exchange in query order, and
+    the AND over the hash functions must equal bulk_contains on the whole index"""
+    import torch
+    import torch.distributed as dist
+    from charon_amd import shard
+    from oracle import pyoracle as po
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    r = util.rng(5)
+    gs = [util.random_seq(r, 3000) for _ in range(70)]
+    oidx = util.build_oracle_index(po, [[g] for g in gs], [i % 2 for i in range(70)], ["host", "microbial"], bin_size=5003)
+    words, W, S = oidx.words().reshape(-1, oidx.bin_words), oidx.bin_words, oidx.bin_size
+    splits = shard.row_splits(S, world)
+    mins = np.concatenate([po.minimisers(g[:700].decode()) for g in gs[rank * 5:rank * 5 + 5 + rank]])  # ranks hold different amounts
+    rows = np.array([[po.lib().orc_hash_and_fit(int(v), i, S) for i in range(3)] for v in mins], dtype=np.int64)
+    owner = np.searchsorted(np.array(splits[1:]), rows, side="right")
+    order = np.lexsort((np.arange(rows.size), owner.ravel()))          # grouped by owner, original probe order inside a group
+    send = torch.from_numpy((rows.ravel()[order] - np.array(splits)[owner.ravel()[order]]).astype(np.int64))
+    send_counts = [int((owner == o).sum()) for o in range(world)]
+    qin, recv_counts = shard.all_to_all_v(dist, send, send_counts)
+    lo = splits[rank]
+    served = torch.from_numpy(words[lo + qin.numpy()].astype(np.int64).ravel())   # the owner's gather
+    back, back_counts = shard.all_to_all_v(dist, served, recv_counts, width=W)
+    ok = back_counts == send_counts
+    got = np.zeros((rows.size, W), np.uint64)
+    got[order] = back.numpy().view(np.uint64).reshape(-1, W)
+    got = got.reshape(len(mins), 3, W)
+    anded = got[:, 0] & got[:, 1] & got[:, 2]
+    want = np.stack([oidx.bulk_contains(int(v)) for v in mins])
+    ok = ok and bool(np.array_equal(anded, want))
+    np.save(os.path.join(outdir, "x%d.npy" % rank), np.array([int(ok), len(mins)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sparse_row_sharded_exchange_two_ranks(oracle_lib):
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_sparse_worker, args=(2, os.path.join(d, "init"), d), nprocs=2, join=True)
+        a, b = np.load(os.path.join(d, "x0.npy")), np.load(os.path.join(d, "x1.npy"))
+    assert a[0] == 1 and b[0] == 1 and a[1] != b[1]
