@@ -35,6 +35,8 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <unordered_set>

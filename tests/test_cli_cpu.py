@@ -143,3 +143,30 @@ def test_gzip_size_emulator_equals_the_linked_zlib(tmp_path):
     for ln in lines[1:]:
         name, z, e = ln.split("\t")
         assert z == e, ln
+
+
+def test_truncated_or_corrupt_gz_input_is_an_error(tmp_path):
+    """a cut-off or CRC-corrupt .gz must fail loudly (the reference's seqan3 / zlib stream throws), never pass for a shorter file"""
+    data = open(os.path.join(G, "cfg1_reads.fastq.gz"), "rb").read()
+    rc, out, _ = run(["_records", os.path.join(G, "cfg1_reads.fastq.gz")])
+    assert rc == 0 and out.count("\n") == 200
+    cut = tmp_path / "cut.fastq.gz"
+    cut.write_bytes(data[:len(data) * 2 // 3])
+    rc, out, err = run(["_records", str(cut)])
+    assert rc != 0 and "gzip read error" in err
+    bad = bytearray(data)
+    bad[-6] ^= 0x5A  # inside the CRC32 trailer
+    crc = tmp_path / "crc.fastq.gz"
+    crc.write_bytes(bytes(bad))
+    rc, out, err = run(["_records", str(crc)])
+    assert rc != 0 and "gzip read error" in err
+    # the same records through the mapped-file path (plain text) and through zlib (CHARON_NO_MMAP) are identical
+    import gzip
+    plain = tmp_path / "plain.fastq"
+    plain.write_bytes(gzip.decompress(data))
+    a = subprocess.run([EXE, "_records", str(plain), "50", "4096"], stdout=subprocess.PIPE)
+    b = subprocess.run([EXE, "_records", str(plain), "50", "4096"], stdout=subprocess.PIPE, env=dict(os.environ, CHARON_NO_MMAP="1"))
+    assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and a.stdout.count(b"\n") == 200
+    empty = tmp_path / "empty.fastq"
+    empty.write_bytes(b"")
+    assert run(["_records", str(empty)])[0] == 0
