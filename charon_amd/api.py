@@ -34,7 +34,8 @@ class Model(C.Structure):
                 ("min_length", C.c_uint32), ("min_compression", C.c_float), ("confidence_threshold", C.c_int8),
                 ("min_hits", C.c_uint8), ("paired", C.c_uint8), ("host_index", C.c_uint8),
                 ("confidence_probability_threshold", C.c_float), ("host_unique_prop_lo_threshold", C.c_float),
-                ("min_proportion_difference", C.c_float), ("min_prob_difference", C.c_float)]
+                ("min_proportion_difference", C.c_float), ("min_prob_difference", C.c_float),
+                ("dist", C.c_uint32), ("pos_params", C.POINTER(C.c_float)), ("neg_params", C.POINTER(C.c_float))]
 
 
 class StreamCfg(C.Structure):
@@ -221,9 +222,23 @@ class Index:
             self.h = None
 
 
-def default_model(num_categories, host_index, paired=False, **overrides):
+DIST = {"kde": 0, "gamma": 1, "beta": 2}
+# Model defaults of include/classify_stats.hpp:265-268: gamma (shape, loc, scale), beta (alpha, beta, -)
+DIST_DEFAULTS = {"gamma": ((25.0, 0.0, 0.02), (10.0, 0.0, 0.005)), "beta": ((6.0, 4.0, 0.0), (6.0, 40.0, 0.0))}
+
+
+def default_model(num_categories, host_index, paired=False, dist="kde", pos_params=None, neg_params=None, **overrides):
+    """paired=True selects call_category (paired dehost, every classify run).  dist gamma / beta: per-category parameter triples
+    (default: the reference's) instead of the KDE datasets."""
     m = Model()
     _chk(_L.chn_model_default(C.byref(m), num_categories, host_index, 1 if paired else 0))
+    if dist != "kde":
+        pp = np.ascontiguousarray(pos_params if pos_params is not None else [DIST_DEFAULTS[dist][0]] * num_categories, np.float32)
+        nn = np.ascontiguousarray(neg_params if neg_params is not None else [DIST_DEFAULTS[dist][1]] * num_categories, np.float32)
+        m._keep = (pp, nn)
+        m.dist = DIST[dist]
+        m.pos_params = pp.ctypes.data_as(C.POINTER(C.c_float))
+        m.neg_params = nn.ctypes.data_as(C.POINTER(C.c_float))
     for k, v in overrides.items():
         setattr(m, k, v)
     return m

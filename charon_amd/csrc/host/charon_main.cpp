@@ -13,7 +13,8 @@
 // gzip compression ratio (src/utils.cpp:114-124, zlib, computed in an OpenMP loop overlapping nothing yet).
 // --extract writes <prefix>_<category>[_1|_2]<ext>.gz like src/dehost_main.cpp:515-536 / include/result.hpp:118-128 (plain gzip
 // members; record layout as seqan3's sequence_file_output, which is recalled, not verified).
-// Not implemented: gamma/beta distributions (rejected like an unknown --dist), .bz2 input.
+// `charon classify` (src/classify_main.cpp) shares the loop: call_category for every read, gamma / beta models (--dist), its own defaults.
+// Not implemented: .bz2 input.
 #include <algorithm>
 #include <cerrno>
 #include <climits>
@@ -79,7 +80,7 @@ int main(int argc, char **argv) {
         std::cout << "Charon: Dehost metagenomic reads\nUsage: charon [OPTIONS] SUBCOMMAND\n\nOptions:\n  -h,--help   Print this help message and exit\n  -V,--version   Show version\n\n"
                      "Subcommands:\n  index    Build an index (IBF) for a number of references split into a small number of bins.\n"
                      "  dehost   Dehost read file into host and other using index.\n"
-                     "  (classify is not part of the MI355X hot-path build)\n";
+                     "  classify Classify read file using index.\n";
         return 0;
     }
     if (sub == "_gzsize") {  // hidden diagnostic: per record, gzip size by the linked zlib and by the size emulator (no GPU involved)
@@ -134,8 +135,9 @@ int main(int argc, char **argv) {
             return 1;
         }
     }
-    if (sub != "dehost") { std::cerr << "The following argument was not expected: " << sub << "\nRun with --help for more information.\n"; return 109; }
+    if (sub != "dehost" && sub != "classify") { std::cerr << "The following argument was not expected: " << sub << "\nRun with --help for more information.\n"; return 109; }
     DehostArguments opt;
+    if (sub == "classify") opt.set_classify_defaults();
     try {
         if (const char *e = std::getenv("CHARON_BATCH_READS")) opt.batch_reads = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
         if (const char *e = std::getenv("CHARON_BATCH_BASES")) opt.batch_bases = std::max<uint64_t>(1 << 20, std::strtoull(e, nullptr, 10)) & ~63ULL;

@@ -87,7 +87,8 @@ int chn_index_destroy(chn_index *idx);
 /* ---- model --------------------------------------------------------------------------------------------
  * Replaces: StatsModel + Model + KDEParams as read by ReadEntry::apply_model / call_host / call_category
  * (include/classify_stats.hpp:210-254,370-389,395-519; include/read_entry.hpp:157-279).
- * Only dist == "kde" runs on the device (the default, include/dehost_arguments.hpp:27). */
+ * `paired` selects the caller: 0 = call_host (single-end dehost), 1 = call_category (paired dehost and every
+ * `charon classify` run, include/read_entry.hpp:281-285). */
 typedef struct chn_model {
     uint32_t struct_size;
     uint32_t num_categories;
@@ -112,7 +113,18 @@ typedef struct chn_model {
     float host_unique_prop_lo_threshold;
     float min_proportion_difference;
     float min_prob_difference;
+    /* Parametric models (`charon classify`, `charon dehost --dist gamma|beta`; include/classify_stats.hpp:116-208,289-339,
+     * 377-381).  dist == CHN_DIST_KDE: the KDE datasets above are used and the two pointers are ignored.  Otherwise per
+     * category three floats for the pos and three for the neg distribution: gamma (shape, loc, scale) -- reference defaults
+     * pos {25, 0, 0.02}, neg {10, 0, 0.005} (:265-266) -- or beta (alpha, beta, unused) -- defaults pos {6, 4}, neg {6, 40}
+     * (:267-268); the KDE datasets may then be NULL / empty. */
+    uint32_t dist;
+    const float *pos_params;      /* [C][3] */
+    const float *neg_params;      /* [C][3] */
 } chn_model;
+#define CHN_DIST_KDE 0u
+#define CHN_DIST_GAMMA 1u
+#define CHN_DIST_BETA 2u
 
 /* Fill `m` with the reference defaults (default KDE tables of src/dehost_main.cpp:23-206, sorted; thresholds
  * of include/dehost_arguments.hpp).  Pointers refer to static storage inside the library. */

@@ -564,7 +564,18 @@ struct DehostArguments {
     uint8_t threads = 1, verbosity = 0;
     uint8_t min_hits = 0;  // StatsModel::min_hits_ is never initialised in the reference (UB); 0 here
     bool skip_gzip = false;  // oracle-only switch: leave `compression` at 0 (hot-path-only timing)
+    // `charon classify` (src/classify_main.cpp, include/classify_arguments.hpp): the same loop and Result state machine, every read
+    // goes through ReadEntry::classify (call_category); only the defaults differ (see classify_defaults below)
+    bool classify_mode = false;
 };
+inline DehostArguments classify_defaults() {  // include/classify_arguments.hpp:19-29 mapped onto the shared argument struct
+    DehostArguments o;
+    o.classify_mode = true; o.dist = "beta"; o.min_quality = 10.0f; o.min_length = 140; o.min_compression = 0.15f;
+    o.confidence_threshold = 2; o.min_proportion_difference = 0.0f;
+    // the remaining StatsModel members are not set by the ClassifyArguments constructor (include/classify_stats.hpp:428-440)
+    // and call_category does not read them
+    return o;
+}
 
 // default KDE training tables: src/dehost_main.cpp:23-206 (sorted by the KDEParams constructor,
 // include/classify_stats.hpp:214-218).  Loaded from tests/golden/default_kde.txt-style data at run time.
@@ -622,19 +633,90 @@ struct TrainingData {  // include/classify_stats.hpp:34-114
     void clear() { pos.clear(); neg.clear(); }
 };
 
-struct Model {  // include/classify_stats.hpp:261-393 (KDE only; gamma/beta are out of scope)
+// mean / variance helpers of include/classify_stats.hpp:20-32 (double sum of float data; the variance lambda's accumulator is a float)
+inline double mean_of(const std::vector<float> &v) {
+    double sum = 0.0;
+    for (float x : v) sum += x;
+    return v.empty() ? 0 : sum / v.size();
+}
+inline double variance_of(const std::vector<float> &v, double mean) {
+    double sum = 0.0;
+    for (float val : v) { const float accumulator = (float)sum; sum = accumulator + ((val - mean) * (val - mean)); }
+    return v.size() <= 1 ? 0 : sum / (v.size() - 1);
+}
+// stats::dgamma(x, shape, scale) / stats::dbeta(x, a, b) of kthohr/stats 3.4.0 called with float arguments
+// (include/classify_stats.hpp:377-381) [3P-recall: statslib is absent from the image -- parity unpinned]: sanity checks -> NaN,
+// the boundary cases of the support, otherwise exp(log-density), evaluated in float.  tests/test_oracle_kat.py cross-checks the
+// densities against scipy.stats.
+inline float stats_dgamma(float x, float shape, float scale) {
+    if (std::isnan(x) || std::isnan(shape) || std::isnan(scale) || shape < 0.0f || scale < 0.0f) return std::numeric_limits<float>::quiet_NaN();
+    if (x < 0.0f) return 0.0f;
+    if (x == 0.0f) return shape < 1.0f ? std::numeric_limits<float>::infinity() : (shape > 1.0f ? 0.0f : 1.0f / scale);
+    if (std::isinf(x)) return 0.0f;
+    return std::exp(-std::lgamma(shape) - shape * std::log(scale) + (shape - 1.0f) * std::log(x) - x / scale);
+}
+inline float stats_dbeta(float x, float a, float b) {
+    const float inf = std::numeric_limits<float>::infinity();
+    if (std::isnan(x) || std::isnan(a) || std::isnan(b) || a < 0.0f || b < 0.0f) return std::numeric_limits<float>::quiet_NaN();
+    if (x < 0.0f || x > 1.0f) return 0.0f;
+    if (a == 0.0f && b == 0.0f) return (x == 0.0f || x == 1.0f) ? inf : 0.0f;
+    if (a == 0.0f || (std::isinf(b) && !std::isinf(a))) return x == 0.0f ? inf : 0.0f;
+    if (b == 0.0f || (std::isinf(a) && !std::isinf(b))) return x == 1.0f ? inf : 0.0f;
+    if (std::isinf(a) && std::isinf(b)) return x == 0.5f ? inf : 0.0f;
+    if (x == 0.0f) return a < 1.0f ? inf : (a > 1.0f ? 0.0f : b);
+    if (x == 1.0f) return b < 1.0f ? inf : (b > 1.0f ? 0.0f : a);
+    return std::exp(-(std::lgamma(a) + std::lgamma(b) - std::lgamma(a + b)) + (a - 1.0f) * std::log(x) + (b - 1.0f) * std::log(1.0f - x));
+}
+struct GammaParams {  // include/classify_stats.hpp:116-157
+    float shape, loc, scale;
+    void fit(const std::vector<float> &data) {  // :127-137
+        const double mu = mean_of(data), ln_mu = std::log(mu);
+        double sum_ln = 0.0;
+        for (float n : data) sum_ln += std::log(n);  // std::log(float) -> float, accumulated in double
+        const double mean_ln = data.empty() ? 0 : sum_ln / data.size();
+        const double s = ln_mu - mean_ln;
+        shape = (float)((3 - s + std::sqrt((s - 3) * (s - 3) + 24 * s)) / (12 * s));
+        scale = (float)(mu / shape);
+    }
+    void fit_loc(const std::vector<float> &data) { loc = (float)(mean_of(data) - (shape * scale)); }  // :139-142
+};
+struct BetaParams {  // :159-208
+    float alpha, beta, loc;
+    void fit(const std::vector<float> &data) {  // :171-191 (the asserts vanish in a release build)
+        const double mu = mean_of(data), var = variance_of(data, mu);
+        alpha = (float)(mu * ((mu * (1 - mu) / var) - 1));
+        beta = (float)((1 - mu) * ((mu * (1 - mu) / var) - 1));
+    }
+};
+
+struct Model {  // include/classify_stats.hpp:261-393
     bool ready = false;
+    std::string dist = "kde";
+    GammaParams g_pos{25, 0, 0.02f}, g_neg{10, 0, 0.005f};  // :265-266
+    BetaParams b_pos{6, 4, 0}, b_neg{6, 40, 0};              // :267-268
     KDEParams k_pos, k_neg;
     Model() : k_pos(default_tables().pos, 0.1f), k_neg(default_tables().neg, 0.001f) {}
-    void train(TrainingData &td) {  // :341-368
-        if (td.pos_complete) k_pos.fit(td.pos);
-        if (td.neg_complete) k_neg.fit(td.neg);
+    explicit Model(const std::string &d) : dist(d), k_pos(default_tables().pos, 0.1f), k_neg(default_tables().neg, 0.001f) {}
+    void train(TrainingData &td) {  // :289-368
+        if (dist == "kde") {
+            if (td.pos_complete) k_pos.fit(td.pos);
+            if (td.neg_complete) k_neg.fit(td.neg);
+        } else if (dist == "beta") {
+            if (td.pos_complete) b_pos.fit(td.pos);
+            if (td.neg_complete) b_neg.fit(td.neg);
+        } else {  // gamma: an incomplete neg set still moves the default distribution's location (:306-312)
+            if (td.pos_complete) g_pos.fit(td.pos);
+            if (td.neg_complete) g_neg.fit(td.neg); else g_neg.fit_loc(td.neg);
+        }
         ready = true;
         td.clear();
     }
     ProbPair prob(const float &x) const {  // :370-389
         const float p_err = dexp300(x);
-        float p_pos = k_pos.prob(x), p_neg = k_neg.prob(x);
+        float p_pos, p_neg;
+        if (dist == "kde") { p_pos = k_pos.prob(x); p_neg = k_neg.prob(x); }
+        else if (dist == "gamma") { p_pos = stats_dgamma(x - g_pos.loc, g_pos.shape, g_pos.scale); p_neg = stats_dgamma(x - g_neg.loc, g_neg.shape, g_neg.scale); }
+        else { p_pos = stats_dbeta(x, b_pos.alpha, b_pos.beta); p_neg = stats_dbeta(x, b_neg.alpha, b_neg.beta); }
         if (x == 1) p_pos = 1;
         const float total = p_err + p_pos + p_neg;
         ProbPair pp; pp.pos = p_pos / total; pp.neg = (p_err + p_neg) / total;
@@ -662,7 +744,7 @@ struct StatsModel {  // include/classify_stats.hpp:395-584
           host_unique_prop_lo_threshold_(opt.host_unique_prop_lo_threshold),
           min_proportion_difference_(opt.min_proportion_difference), min_prob_difference_(opt.min_prob_difference) {
         for (unsigned i = 0; i < summary.num_categories(); ++i) {
-            models_.emplace_back();
+            models_.emplace_back(opt.dist);
             TrainingData td; td.num_reads_to_fit = opt.num_reads_to_fit;
             training_data_.push_back(td);
         }
@@ -1016,10 +1098,11 @@ inline void dehost_run(DehostArguments opt, const Index &index, std::ostream &os
         // critical(add_read_to_results): serial, in input order (= the reference at -t 1)
         for (size_t i = 0; i < n; ++i) {
             if (skip[i]) continue;
-            result.add_read(entries[i], /*dehost=*/!opt.is_paired);  // paired path calls add_paired_read without dehost=true (:470)
+            // the paired dehost path calls add_paired_read without dehost=true (:470); classify never passes it (src/classify_main.cpp:180)
+            result.add_read(entries[i], /*dehost=*/!opt.is_paired && !opt.classify_mode);
         }
     }
-    result.complete(!opt.is_paired);  // :379 complete(true) / :475 complete()
+    result.complete(!opt.is_paired && !opt.classify_mode);  // :379 complete(true) / :475 complete()
 }
 
 // minimal `charon index` restatement (src/index_main.cpp:75-305) to fabricate test indexes.

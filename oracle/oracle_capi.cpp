@@ -124,7 +124,7 @@ uint64_t orc_sd_get_int(void *h, uint64_t bit) { return ((Index *)h)->ef.get_int
 struct OrcThresholds {
     float min_quality; uint32_t min_length; float min_compression; uint8_t confidence_threshold;
     float confidence_probability_threshold, host_unique_prop_lo_threshold, min_proportion_difference, min_prob_difference;
-    uint8_t min_hits; uint8_t paired; uint8_t with_gzip; uint8_t pad;
+    uint8_t min_hits; uint8_t paired; uint8_t with_gzip; uint8_t dist;  // dist: 0 kde, 1 gamma, 2 beta (default parameters)
 };
 double orc_process_reads(void *h, const char *seqs, const uint64_t *offsets, uint64_t n, const uint32_t *mate_split,
                          const char *quals, float mq_const, const OrcThresholds *thr, int threads, uint32_t *num_hashes,
@@ -138,6 +138,7 @@ double orc_process_reads(void *h, const char *seqs, const uint64_t *offsets, uin
     opt.host_unique_prop_lo_threshold = thr->host_unique_prop_lo_threshold;
     opt.min_proportion_difference = thr->min_proportion_difference; opt.min_prob_difference = thr->min_prob_difference;
     opt.min_hits = thr->min_hits;
+    opt.dist = thr->dist == 1 ? "gamma" : thr->dist == 2 ? "beta" : "kde";
     StatsModel model(opt, idx->summary);
     const unsigned C = idx->summary.num_categories();
     const uint8_t host = idx->summary.host_category_index();
@@ -171,10 +172,17 @@ double orc_process_reads(void *h, const char *seqs, const uint64_t *offsets, uin
 }
 
 // full `charon dehost` on files -> TSV text into a caller buffer (returns bytes needed)
+uint64_t orc_dehost_files_dist(void *h, const char *reads1, const char *reads2, int run_extract, int chunk_size, int threads,
+                               int num_reads_to_fit, float min_quality, int confidence, const char *dist, char *out, uint64_t cap);
 uint64_t orc_dehost_files(void *h, const char *reads1, const char *reads2, int run_extract, int chunk_size, int threads,
                           int num_reads_to_fit, float min_quality, int confidence, char *out, uint64_t cap) {
+    return orc_dehost_files_dist(h, reads1, reads2, run_extract, chunk_size, threads, num_reads_to_fit, min_quality, confidence, "kde", out, cap);
+}
+uint64_t orc_dehost_files_dist(void *h, const char *reads1, const char *reads2, int run_extract, int chunk_size, int threads,
+                               int num_reads_to_fit, float min_quality, int confidence, const char *dist, char *out, uint64_t cap) {
     Index *idx = (Index *)h;
     DehostArguments opt;
+    if (dist && dist[0]) opt.dist = dist;
     opt.read_file = reads1;
     if (reads2 && reads2[0]) { opt.read_file2 = reads2; opt.is_paired = true; opt.min_length = 80; }
     opt.run_extract = run_extract != 0;
@@ -185,6 +193,31 @@ uint64_t orc_dehost_files(void *h, const char *reads1, const char *reads2, int r
     std::string s = os.str();
     if (out && cap) std::memcpy(out, s.data(), std::min<uint64_t>(cap, s.size()));
     return s.size();
+}
+
+// full `charon classify` on files -> TSV text (classify defaults of include/classify_arguments.hpp; dist "beta" / "gamma")
+uint64_t orc_classify_files(void *h, const char *reads1, const char *reads2, int run_extract, int chunk_size, int threads,
+                            int num_reads_to_fit, const char *dist, char *out, uint64_t cap) {
+    Index *idx = (Index *)h;
+    DehostArguments opt = classify_defaults();
+    opt.read_file = reads1;
+    if (reads2 && reads2[0]) { opt.read_file2 = reads2; opt.is_paired = true; opt.min_length = 80; }
+    opt.run_extract = run_extract != 0;
+    opt.chunk_size = (uint8_t)chunk_size; opt.threads = (uint8_t)threads; opt.num_reads_to_fit = (uint16_t)num_reads_to_fit;
+    if (dist && dist[0]) opt.dist = dist;
+    std::ostringstream os;
+    try { dehost_run(opt, *idx, os); } catch (std::exception &e) { std::fprintf(stderr, "orc_classify_files: %s\n", e.what()); return 0; }
+    std::string s = os.str();
+    if (out && cap) std::memcpy(out, s.data(), std::min<uint64_t>(cap, s.size()));
+    return s.size();
+}
+// the two statslib densities, for the scipy cross-check: kind 1 = dgamma(x, shape p0, scale p1), 2 = dbeta(x, alpha p0, beta p1)
+float orc_density(int kind, float x, float p0, float p1) { return kind == 1 ? stats_dgamma(x, p0, p1) : stats_dbeta(x, p0, p1); }
+// GammaParams::fit / fit_loc and BetaParams::fit on caller data: out = {shape, loc, scale} or {alpha, beta, 0}
+void orc_fit(int kind, const float *data, uint64_t n, int loc_only, float *out) {
+    std::vector<float> v(data, data + n);
+    if (kind == 1) { GammaParams g{out[0], out[1], out[2]}; if (loc_only) g.fit_loc(v); else g.fit(v); out[0] = g.shape; out[1] = g.loc; out[2] = g.scale; }
+    else { BetaParams b{out[0], out[1], 0}; b.fit(v); out[0] = b.alpha; out[1] = b.beta; out[2] = 0; }
 }
 
 int orc_num_threads() {

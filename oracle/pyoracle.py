@@ -21,12 +21,19 @@ class Thresholds(C.Structure):
                 ("confidence_threshold", C.c_uint8), ("confidence_probability_threshold", C.c_float),
                 ("host_unique_prop_lo_threshold", C.c_float), ("min_proportion_difference", C.c_float),
                 ("min_prob_difference", C.c_float), ("min_hits", C.c_uint8), ("paired", C.c_uint8),
-                ("with_gzip", C.c_uint8), ("pad", C.c_uint8)]
+                ("with_gzip", C.c_uint8), ("dist", C.c_uint8)]
 
 
 def default_thresholds(paired=False, with_gzip=False):
     return Thresholds(15.0, 80 if paired else 140, 0.0, 7, 0.0, 0.05, 0.04, 0.0, 0, 1 if paired else 0,
                       1 if with_gzip else 0, 0)
+
+
+def classify_thresholds(paired=False, dist="beta", with_gzip=False):
+    """`charon classify` defaults (include/classify_arguments.hpp:19-29): call_category for single-end reads too (the `paired`
+    field of this struct selects call_category), min_quality 10, min_compression 0.15, confidence 2, min_proportion_diff 0"""
+    return Thresholds(10.0, 80 if paired else 140, 0.15, 2, 0.0, 0.05, 0.0, 0.0, 0, 1, 1 if with_gzip else 0,
+                      {"kde": 0, "gamma": 1, "beta": 2}[dist])
 
 
 _lib = None
@@ -81,6 +88,15 @@ def lib():
         L.orc_process_reads.restype = C.c_double
         L.orc_process_reads.argtypes = [C.c_void_p, C.c_char_p, u64p, C.c_uint64, C.c_void_p, C.c_char_p, C.c_float,
                                         C.POINTER(Thresholds), C.c_int] + [C.c_void_p] * 10
+        L.orc_dehost_files_dist.restype = C.c_uint64
+        L.orc_dehost_files_dist.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_char_p,
+                                            C.c_char_p, C.c_uint64]
+        L.orc_classify_files.restype = C.c_uint64
+        L.orc_classify_files.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_uint64]
+        L.orc_density.restype = C.c_float
+        L.orc_density.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float]
+        L.orc_fit.restype = None
+        L.orc_fit.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
         L.orc_dehost_files.restype = C.c_uint64
         L.orc_dehost_files.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                        C.c_int, C.c_char_p, C.c_uint64]
@@ -190,15 +206,35 @@ class Index:
         return out
 
     def dehost_files(self, reads1, reads2="", run_extract=False, chunk_size=100, threads=1, num_reads_to_fit=5000,
-                     min_quality=15.0, confidence=7):
-        need = lib().orc_dehost_files(self.h, reads1.encode(), reads2.encode(), int(run_extract), chunk_size, threads,
-                                      num_reads_to_fit, min_quality, confidence, None, 0)
+                     min_quality=15.0, confidence=7, dist="kde"):
+        args = (self.h, reads1.encode(), reads2.encode(), int(run_extract), chunk_size, threads, num_reads_to_fit, min_quality, confidence,
+                dist.encode())
+        need = lib().orc_dehost_files_dist(*args, None, 0)
         buf = C.create_string_buffer(int(need) + 1)
-        lib().orc_dehost_files(self.h, reads1.encode(), reads2.encode(), int(run_extract), chunk_size, threads,
-                               num_reads_to_fit, min_quality, confidence, buf, need)
+        lib().orc_dehost_files_dist(*args, buf, need)
+        return buf.raw[:need].decode()
+
+    def classify_files(self, reads1, reads2="", run_extract=False, chunk_size=100, threads=1, num_reads_to_fit=5000, dist="beta"):
+        args = (self.h, reads1.encode(), reads2.encode(), int(run_extract), chunk_size, threads, num_reads_to_fit, dist.encode())
+        need = lib().orc_classify_files(*args, None, 0)
+        buf = C.create_string_buffer(int(need) + 1)
+        lib().orc_classify_files(*args, buf, need)
         return buf.raw[:need].decode()
 
     def free(self):
         if self.h:
             lib().orc_index_free(self.h)
             self.h = None
+
+
+def density(kind, x, p0, p1):
+    """stats::dgamma(x, shape p0, scale p1) (kind "gamma") / stats::dbeta(x, alpha p0, beta p1) (kind "beta") as the oracle restates them"""
+    return float(lib().orc_density(1 if kind == "gamma" else 2, x, p0, p1))
+
+
+def fit(kind, data, start, loc_only=False):
+    """GammaParams::fit / fit_loc, BetaParams::fit (include/classify_stats.hpp:127-142,171-191) -> 3 floats"""
+    d = np.ascontiguousarray(data, np.float32)
+    out = np.array(list(start) + [0.0] * (3 - len(start)), np.float32)
+    lib().orc_fit(1 if kind == "gamma" else 2, d.ctypes.data, d.size, int(loc_only), out.ctypes.data)
+    return out

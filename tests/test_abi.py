@@ -21,7 +21,7 @@ def test_struct_layout_matches_header():
     import charon_amd.api as api
     # sizes computed by hand from the header's field list (natural alignment)
     assert ctypes.sizeof(api.IndexDesc) == 336
-    assert ctypes.sizeof(api.Model) == 88
+    assert ctypes.sizeof(api.Model) == 104  # + dist, pos_params, neg_params (round 2)
     assert ctypes.sizeof(api.StreamCfg) == 24
     assert ctypes.sizeof(api.Batch) == 88
     assert ctypes.sizeof(api.Result) == 64

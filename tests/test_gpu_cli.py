@@ -15,10 +15,10 @@ G = os.path.join(util.ROOT, "tests", "golden")
 EXE = os.path.join(util.ROOT, "charon_amd", "bin", "charon")
 
 
-def run_cli(args, cwd, env_extra=None):
+def run_cli(args, cwd, env_extra=None, sub="dehost"):
     env = dict(os.environ)
     env.update(env_extra or {})
-    p = subprocess.run([EXE, "dehost"] + args + ["--log", os.path.join(cwd, "charon.log")], cwd=cwd, env=env, stdout=subprocess.PIPE,
+    p = subprocess.run([EXE, sub] + args + ["--log", os.path.join(cwd, "charon.log")], cwd=cwd, env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE)
     return p.returncode, p.stdout.decode(), p.stderr.decode()
 
@@ -309,6 +309,78 @@ def test_cli_long_reads_compression_column(tmp_path, oracle_lib):
     want = oidx.dehost_files(str(tmp_path / "long.fastq"))
     for env in ({}, {"CHARON_ZLIB_ONLY": "1"}):
         rc, out, err = run_cli(["--db", str(tmp_path / "l.idx"), "-t", "4", str(tmp_path / "long.fastq")], str(tmp_path), env)
+        assert rc == 0, err
+        assert_same_tsv(out, want)
+    oidx.free()
+
+
+def test_cli_classify_gamma_beta(tmp_path, oracle_lib):
+    """`charon classify` (src/classify_main.cpp): call_category for single-end reads too, beta (default) / gamma models, its own
+    threshold defaults incl. min_compression 0.15 (so the gzip column matters), dropped first read; --extract trains the models
+    (method-of-moments fits, include/classify_stats.hpp:127-142,171-191) and re-classifies the cached reads; `charon dehost
+    --dist gamma` shares the machinery.  TSV == the oracle's classify."""
+    r = util.rng(33)
+    gs = [util.random_seq(r, 8000) for _ in range(3)]
+    for i, g in enumerate(gs):
+        with open(tmp_path / ("g%d.fa" % i), "w") as f:
+            f.write(">g%d\n%s\n" % (i, g.decode()))
+    oidx = oracle_lib.Index.from_fasta([(str(tmp_path / "g0.fa"), "human"), (str(tmp_path / "g1.fa"), "bacteria"),
+                                        (str(tmp_path / "g2.fa"), "virus")], ["bacteria", "human", "virus"])
+    oidx.store(str(tmp_path / "c.idx"))
+    reads = util.sample_reads(r, gs, 400, (120, 900), sub_rate=0.03, random_fraction=0.15) + [b"ACGT" * 100, b"A" * 400]
+    with open(tmp_path / "r.fastq", "w") as f:
+        for i, s in enumerate(reads):
+            q = "".join(chr(33 + int(x)) for x in r.integers(8, 41, len(s)))
+            f.write("@read%d extra\n%s\n+\n%s\n" % (i, s.decode(), q))
+    fq, db = str(tmp_path / "r.fastq"), str(tmp_path / "c.idx")
+    for dist in ("beta", "gamma"):
+        want = oidx.classify_files(fq, dist=dist)
+        rc, out, err = run_cli(["--db", db] + ([] if dist == "beta" else ["--dist", dist]) + [fq], str(tmp_path), sub="classify")
+        assert rc == 0, err
+        assert_same_tsv(out, want)
+        assert len(out.strip().split("\n")) == len(reads) - 1  # the first read is dropped here as well
+        calls = {ln.split("\t")[2] for ln in out.strip().split("\n")}
+        assert {"bacteria", "human", "virus"} <= calls
+    # low-complexity reads fail classify's min_compression 0.15 gate
+    last = out.strip().split("\n")[-1].split("\t")
+    assert last[0] == "U" and float(last[7]) < 0.15
+    # training: --extract with a small num_reads_to_fit (fits happen, cached reads are re-classified), small GPU batches
+    for dist in ("beta", "gamma"):
+        want = oidx.classify_files(fq, run_extract=True, num_reads_to_fit=25, dist=dist)
+        rc, out, err = run_cli(["--db", db, "-d", dist, "--extract", "all", "--num_reads_to_fit", "25", "-p", str(tmp_path / ("x" + dist)), fq],
+                               str(tmp_path), {"CHARON_BATCH_READS": "48"}, sub="classify")
+        assert rc == 0, err
+        assert_same_tsv(out, want)
+        assert os.path.exists(tmp_path / ("x%s_bacteria.fastq.gz" % dist))
+    # kde is not a classify distribution (src/classify_main.cpp:338-341): logged, no rows, exit status 0
+    rc, out, err = run_cli(["--db", db, "-d", "kde", fq], str(tmp_path), sub="classify")
+    assert rc == 0 and out == "" and "Supported distributions are [gamma , beta]" in open(tmp_path / "charon.log").read()
+    # paired classify
+    m2 = util.sample_reads(r, gs, 120, (100, 250), sub_rate=0.02)
+    m1 = util.sample_reads(r, gs, 120, (100, 250), sub_rate=0.02)
+    for name, mates, tag in (("p_1.fastq", m1, "/1"), ("p_2.fastq", m2, "/2")):
+        with open(tmp_path / name, "w") as f:
+            for i, s in enumerate(mates):
+                f.write("@pr%d%s\n%s\n+\n%s\n" % (i, tag, s.decode(), "I" * len(s)))
+    want = oidx.classify_files(str(tmp_path / "p_1.fastq"), str(tmp_path / "p_2.fastq"))
+    rc, out, err = run_cli(["--db", db, str(tmp_path / "p_1.fastq"), str(tmp_path / "p_2.fastq")], str(tmp_path), sub="classify")
+    assert rc == 0, err
+    assert_same_tsv(out, want)
+    oidx.free()
+    # dehost accepts gamma / beta as well (src/dehost_main.cpp:538-541)
+    h = [util.random_seq(r, 8000) for _ in range(2)]
+    for i, g in enumerate(h):
+        with open(tmp_path / ("h%d.fa" % i), "w") as f:
+            f.write(">h%d\n%s\n" % (i, g.decode()))
+    oidx = oracle_lib.Index.from_fasta([(str(tmp_path / "h0.fa"), "human"), (str(tmp_path / "h1.fa"), "bacteria")], ["bacteria", "human"])
+    oidx.store(str(tmp_path / "d.idx"))
+    reads = util.sample_reads(r, h, 200, (150, 900), sub_rate=0.03)
+    with open(tmp_path / "d.fastq", "w") as f:
+        for i, s in enumerate(reads):
+            f.write("@d%d\n%s\n+\n%s\n" % (i, s.decode(), "I" * len(s)))
+    for dist in ("gamma", "beta"):
+        want = oidx.dehost_files(str(tmp_path / "d.fastq"), dist=dist)
+        rc, out, err = run_cli(["--db", str(tmp_path / "d.idx"), "--dist", dist, str(tmp_path / "d.fastq")], str(tmp_path))
         assert rc == 0, err
         assert_same_tsv(out, want)
     oidx.free()

@@ -696,3 +696,44 @@ def test_sparse_row_sharded_exchange_equals_replica_mode(api, oracle_lib):
         for sh in shards:
             sh.destroy()
         oidx.free()
+
+
+def test_gamma_and_beta_models_call_category(api, oracle_lib):
+    """`charon classify` / `--dist gamma|beta`: the parametric densities (include/classify_stats.hpp:377-381) in k_model_call, with
+    the classify thresholds (include/classify_arguments.hpp:19-29) and call_category, against the oracle; also a moved neg
+    location (what GammaParams::fit_loc does) and fitted-looking parameters per category"""
+    r = util.rng(61)
+    gs = [util.random_seq(r, 5000) for _ in range(3)]
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [0, 1, 2], ["host", "a", "b"])
+    reads = util.sample_reads(r, gs, 300, (100, 1500), sub_rate=0.04, random_fraction=0.2)
+    g = util.gpu_index_from_oracle(api, oidx)
+    seqs, offs, _ = util.concat(reads)
+    for dist in ("gamma", "beta"):
+        thr = oracle_lib.classify_thresholds(dist=dist)
+        thr.min_compression = 0.0  # the gzip column is a host-side input: both sides gate on 0
+        orc = oidx.process_reads(seqs, offs, thr=thr)
+        m = api.default_model(3, 0, paired=True, dist=dist, min_quality=10.0, min_length=140, min_compression=0.0, confidence_threshold=2,
+                              min_proportion_difference=0.0)
+        gpu = run_gpu(api, g, reads, comp=0.0, model=m)
+        util.assert_parity(gpu, orc)  # host result buffers: the float evaluation of the reference
+        assert len(np.unique(gpu["call"])) >= 3 and np.isfinite(gpu["probs"]).all()
+        # device-resident results: k_model_call's own evaluation (log-density in double) agrees to ~1e-5 in the probability column
+        from charon_amd import pack
+        p = pack.pack_reads(reads)
+        st = api.Stream(g, len(reads), p["n_bases"])
+        st.set_model(m)
+        st.submit_host(p, np.full(len(reads), 40.0, np.float32), np.zeros(len(reads), np.float32))
+        dev = util.download_results(api, st.wait_device(), len(reads), 3)
+        st.destroy()
+        util.assert_parity(dev, orc, prob_tol=2e-5)
+    # the same through dehost's single-end caller (call_host) on a two-category index: `charon dehost --dist gamma`
+    oidx2 = util.build_oracle_index(oracle_lib, [[gs[0]], [gs[1]]], [0, 1], ["host", "microbial"])
+    g2 = util.gpu_index_from_oracle(api, oidx2)
+    for dist in ("gamma", "beta"):
+        thr = oracle_lib.default_thresholds()
+        thr.dist = {"gamma": 1, "beta": 2}[dist]
+        orc = oidx2.process_reads(seqs, offs, thr=thr)
+        gpu = run_gpu(api, g2, reads, comp=0.0, model=api.default_model(2, 0, dist=dist))
+        util.assert_parity(gpu, orc)
+    g.destroy(); g2.destroy()
+    oidx.free(); oidx2.free()

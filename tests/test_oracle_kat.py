@@ -201,3 +201,39 @@ def test_first_read_dropped_without_extract_and_tsv_shape(oracle_lib, tmp_path):
             f.write(">r%d\n%s\n" % (i, s.decode()))
     assert all(x.startswith("U\t") for x in oidx.dehost_files(str(fa)).strip().split("\n"))
     oidx.free()
+
+
+def test_gamma_and_beta_densities_against_scipy(oracle_lib):
+    """`charon classify` models reads with stats::dgamma / stats::dbeta (kthohr/stats 3.4.0, include/classify_stats.hpp:377-381).
+    statslib is not in the image (parity unpinned): the oracle's float restatement is cross-checked against scipy.stats here, and
+    the GPU kernel / the CLI are checked against the oracle in the -m gpu tests."""
+    import scipy.stats as st
+    xs = [1e-6, 0.001, 0.01, 0.05, 0.1, 0.15, 0.2, 0.37, 0.5, 0.75, 0.9, 0.999]
+    for shape, scale in ((25.0, 0.02), (10.0, 0.005), (1.0, 0.3), (0.5, 2.0), (3.7, 0.11)):
+        for x in xs:
+            got, want = oracle_lib.density("gamma", x, shape, scale), st.gamma.pdf(float(np.float32(x)), shape, scale=float(np.float32(scale)))
+            assert got == pytest.approx(want, rel=1e-4, abs=1e-38), (shape, scale, x)  # float log / lgamma / exp: a few 1e-5 in the far tails
+    for a, b in ((6.0, 4.0), (6.0, 40.0), (1.0, 1.0), (0.5, 0.5), (2.5, 1.0), (1.0, 3.0)):
+        for x in xs:
+            got, want = oracle_lib.density("beta", x, a, b), st.beta.pdf(float(np.float32(x)), a, b)
+            assert got == pytest.approx(want, rel=1e-4, abs=1e-38), (a, b, x)
+    # boundaries of the support (statslib's limit values)
+    assert oracle_lib.density("gamma", -0.1, 25, 0.02) == 0 and oracle_lib.density("gamma", 0.0, 25, 0.02) == 0
+    assert oracle_lib.density("gamma", 0.0, 1.0, 0.25) == 4.0 and np.isinf(oracle_lib.density("gamma", 0.0, 0.5, 1.0))
+    assert oracle_lib.density("beta", 0.0, 6, 4) == 0 and oracle_lib.density("beta", 1.0, 6, 4) == 0
+    assert oracle_lib.density("beta", 0.0, 1.0, 3.0) == 3.0 and oracle_lib.density("beta", 1.0, 2.5, 1.0) == 2.5
+    assert oracle_lib.density("beta", 1.5, 6, 4) == 0 and np.isnan(oracle_lib.density("beta", float("nan"), 6, 4))
+    # method-of-moments fits (include/classify_stats.hpp:127-142,171-191)
+    r = np.random.default_rng(3)
+    data = r.gamma(9.0, 0.03, 4000).astype(np.float32)
+    shape, loc, scale = oracle_lib.fit("gamma", data, (25.0, 0.0, 0.02))
+    mu = float(np.mean(data.astype(np.float64)))
+    s = np.log(mu) - float(np.mean(np.log(data).astype(np.float64)))
+    assert shape == pytest.approx((3 - s + np.sqrt((s - 3) ** 2 + 24 * s)) / (12 * s), rel=1e-5) and scale == pytest.approx(mu / shape, rel=1e-5) and loc == 0
+    assert 7.5 < shape < 10.5
+    _, loc2, _ = oracle_lib.fit("gamma", np.zeros(0, np.float32), (10.0, 0.0, 0.005), loc_only=True)
+    assert loc2 == pytest.approx(-0.05)  # what force_ready does to the default neg distribution of a run without --extract
+    d2 = r.beta(5.0, 30.0, 4000).astype(np.float32)
+    alpha, beta, _ = oracle_lib.fit("beta", d2, (6.0, 40.0))
+    m, v = float(np.mean(d2.astype(np.float64))), float(np.var(d2.astype(np.float64), ddof=1))
+    assert alpha == pytest.approx(m * (m * (1 - m) / v - 1), rel=1e-3) and beta == pytest.approx((1 - m) * (m * (1 - m) / v - 1), rel=1e-3)
