@@ -1,22 +1,66 @@
+#!/bin/bash
+# Regenerates the evidence under profiles/rNN on the GPU box (run through gpurun; writes to gpurun_out/profNN, copy what is to be
+# judged into profiles/rNN afterwards):  bash tools/collect_profiles.sh r02 <commit>
 set -e
 export TMPDIR=/tmp
-R=$PWD
-mkdir -p gpurun_out/prof2
+R=${1:-r02}
+COMMIT=${2:-unknown}
+ROOT=$GRAFT_REPO_ROOT
+OUT=$ROOT/gpurun_out/prof_$R
+mkdir -p $OUT
+cd /tmp
+# 1. per-kernel time (rocprofv3 --kernel-trace --stats) of the bench command, with the bench line the same run printed
 for wl in 39g cfg2 cfg5; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$wl -- python3 bench.py --workload $wl --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/prof2/bench_$wl.log 2>&1
-  f=$(find /tmp/p_$wl -name '*kernel_stats.csv' | head -1); cp $f gpurun_out/prof2/kernel_stats_$wl.csv
-  tail -1 gpurun_out/prof2/bench_$wl.log | cut -c1-400
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$wl -- python3 $ROOT/bench.py --workload $wl --steps 8 --warmup 2 --no-cpu-baseline --no-pcie > $OUT/bench_$wl.log 2>&1
+  cp $(find /tmp/p_$wl -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_$wl.csv
+  grep '^{' $OUT/bench_$wl.log | tail -1 > $OUT/bench_under_profiler_$wl.json
 done
+# 2. HBM traffic of the dominant kernel: FETCH_SIZE and WRITE_SIZE in separate passes (MI355X_MICROARCH.md: FETCH_SIZE x2 on gfx950)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 bench.py --workload 39g --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof2/pmc_$c.log 2>&1
-  f=$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)
-  python3 - $f $c <<'PY' > gpurun_out/prof2/pmc_$c.txt
-import csv,sys,collections
-agg=collections.defaultdict(lambda:[0,0.0])
-for r in csv.DictReader(open(sys.argv[1])):
-    k=r["Kernel_Name"].split("(")[0]; agg[k][0]+=1; agg[k][1]+=float(r["Counter_Value"])
-for k,(n,v) in sorted(agg.items(), key=lambda x:-x[1][1]):
-    print(f"{sys.argv[2]},{k},{n},{v/n:.1f}")
-PY
-  head -4 gpurun_out/prof2/pmc_$c.txt
+  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $ROOT/bench.py --workload 39g --steps 3 --warmup 1 --no-cpu-baseline --no-pcie > $OUT/pmc_$c.log 2>&1
+  cp $(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1) $OUT/pmc_$c.csv
 done
+python3 - $OUT $COMMIT <<'PY'
+import csv, sys, json, collections, datetime
+out, commit = sys.argv[1], sys.argv[2]
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for r in csv.DictReader(open("%s/pmc_%s.csv" % (out, c))):
+        k = r["Kernel_Name"].split("(")[0]
+        a = agg[k][c]; a[0] += 1; a[1] += float(r["Counter_Value"])
+with open(out + "/pmc_summary.csv", "w") as f:
+    f.write("kernel,counter,launches,avg_value_KB\n")
+    for k, cs in agg.items():
+        for c, (n, v) in cs.items():
+            f.write("%s,%s,%d,%.1f\n" % (k, c, n, v / n))
+k1 = [k for k in agg if "k_minimise_probe<2, 1, 23>" in k][0]
+fetch_kb, write_kb = agg[k1]["FETCH_SIZE"][1] / agg[k1]["FETCH_SIZE"][0], agg[k1]["WRITE_SIZE"][1] / agg[k1]["WRITE_SIZE"][0]
+traffic = fetch_kb * 1024 * 2 + write_kb * 1024   # gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes
+json.dump({"commit": commit, "date": datetime.date.today().isoformat(),
+           "39g": {"reads_per_launch": 1048576, "read_len": 5000, "kernel": k1, "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
+                   "traffic_bytes": traffic, "note": "FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x 1024, separate --pmc passes of bench.py --workload 39g"}},
+          open(out + "/pmc_traffic.json", "w"), indent=1)
+print("traffic per launch: %.1f GB (fetch %.1f GB after x2, write %.1f GB)" % (traffic / 1e9, fetch_kb * 2048 / 1e9, write_kb * 1024 / 1e9))
+PY
+# 3. gather roofs of this box
+cd $ROOT
+./tools/gather_alloc_bench 39 > $OUT/gather_alloc_microbench.txt 2>&1
+./tools/gather_alloc_bench 1.1 >> $OUT/gather_alloc_microbench.txt 2>&1
+# 4. small batches (BASELINE config 5: launch collapse): paired 2 x 150 b, 8 192 and 65 536 pairs per batch
+for n in 8192 65536; do
+  python3 bench.py --workload cfg5 --reads-per-step $n --steps 200 --warmup 20 --no-cpu-baseline --no-pcie > $OUT/bench_cfg5_$n.json 2>/dev/null
+done
+# 5. other workload shapes + the default line with the CPU baseline
+python3 bench.py --workload 39g --steps 6 --warmup 2 --no-cpu-baseline --read-len 500 --read-len-max 50000 > $OUT/bench_mixed.json 2>/dev/null
+python3 bench.py --workload 39g --shard rows --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_rows_sparse.json 2>/dev/null
+python3 bench.py --workload 39g --shard rows-dense --steps 4 --warmup 1 --no-cpu-baseline > $OUT/bench_rows_dense.json 2>/dev/null
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2>$OUT/bench_default.err
+python3 - $OUT <<'PY'
+import json, sys, glob, os
+for f in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1]); r = d["roofline"]
+        print("%-34s value %8.2f M/s  step %7.3f ms  K1 %7.3f ms  frac %.4f  %.1f Ggather/s" % (os.path.basename(f), d["value"] / 1e6, d["ms_per_step"], r["avg_launch_ms"], r["frac"], r["gathers_per_s"] / 1e9))
+    except Exception as e:
+        print(os.path.basename(f), "failed", e)
+PY
