@@ -45,6 +45,7 @@
 #include "parts/shardx_kernels.inc"
 #include "parts/k3_model_call.inc"
 #include "parts/len_order.inc"
+#include "parts/gzip_tally.inc"
 #include "parts/ef_decode.inc"
 #include "parts/synth_kernels.inc"
 #include "parts/abi_index_model.inc"

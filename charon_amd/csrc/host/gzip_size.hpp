@@ -55,6 +55,20 @@ public:
         return (uint32_t)(18 + ((total_bits_ + 7) >> 3));
     }
 
+    // The same size from the symbol tallies of a ONE-block deflate_slow run that something else did (the GPU: k_gzip_tally,
+    // include/charon_hip.h chn_batch.gzip_tallies): lfreq[286] literal/length code frequencies WITHOUT the end-of-block symbol's
+    // count being trusted (it is set here), dfreq[30] distance code frequencies, n input bytes.
+    uint32_t size_from_tallies(const uint16_t *lfreq, const uint16_t *dfreq, size_t n) {
+        ensure_tables();
+        total_bits_ = 0;
+        init_block();
+        for (int i = 0; i < L_CODES; ++i) lfreq_[i] = lfreq[i];
+        lfreq_[END_BLOCK] = 1;
+        for (int i = 0; i < D_CODES; ++i) dfreq_[i] = dfreq[i];
+        flush_block(n, true, true);
+        return (uint32_t)(18 + ((total_bits_ + 7) >> 3));
+    }
+
 private:
     enum {
         MIN_MATCH = 3, MAX_MATCH = 258, W_SIZE = 32768, MIN_LOOKAHEAD = MAX_MATCH + MIN_MATCH + 1, MAX_DIST = W_SIZE - MIN_LOOKAHEAD,
@@ -487,7 +501,7 @@ private:
     }
 
     // ---- deflate_slow ----------------------------------------------------------------------------------------------------
-    void run(size_t n_in) {
+    void ensure_tables() {
         if (!tables_) {
             init_tables();
             for (int n = 0; n <= 143; ++n) static_llen_[n] = 8;
@@ -496,6 +510,9 @@ private:
             for (int n = 280; n < L_CODES + 2; ++n) static_llen_[n] = 8;
             for (int n = 0; n < D_CODES; ++n) static_dlen_[n] = 5;
         }
+    }
+    void run(size_t n_in) {
+        ensure_tables();
         const uint32_t n = (uint32_t)n_in;
         total_bits_ = 0;
         init_block();

@@ -169,7 +169,20 @@ typedef struct chn_batch {
     const uint32_t *seg2_length; /* [n] or NULL */
     const float *mean_quality;   /* [n] or NULL */
     const float *compression;    /* [n] or NULL */
+    /* Deflate tallies for the `compression` column (get_compression_ratio, src/utils.cpp:114-124) ON THE DEVICE: non-zero = the
+     * longest read (both mates together) to handle there, at most CHN_GZIP_MAX_LEN.  For every read the library then runs zlib's
+     * level-6 deflate_slow as a kernel and returns the literal/length and distance code frequencies of its deflate block
+     * (chn_result.gzip_tallies) -- the caller turns them into the exact gzip size with _tr_flush_block's arithmetic (a few
+     * microseconds per read; charon_amd/csrc/host/gzip_size.hpp).  With tallies requested `compression` is not known when the
+     * call kernel runs: its `compression < min_compression` gate (include/read_entry.hpp:189-191,250-252) is left open and the
+     * CALLER must apply it (call = CHN_NO_CALL where the ratio is below the threshold). */
+    uint32_t gzip_tallies;
+    uint32_t reserved1;
 } chn_batch;
+#define CHN_GZIP_MAX_LEN 16384u
+#define CHN_GZIP_TALLY_WORDS 320u /* per read: [0,286) literal/length code frequencies, [286,316) distance code frequencies,
+                                   * [316] status: 0 = tallies valid, non-zero = not handled on the device (longer than asked for,
+                                   * more than one deflate block): size this read on the host */
 
 /* Per-read results (what a post-processed + classified ReadEntry holds, include/read_entry.hpp:23-32):
  * num_hashes_, counts_[C], unique_counts_[C], probabilities_[C], call_, confidence_score_.
@@ -188,6 +201,7 @@ typedef struct chn_result {
     uint8_t *call;             /* [n] (CHN_NO_CALL = unclassified) */
     uint8_t *confidence;       /* [n] */
     uint8_t *flags;            /* [n] */
+    uint16_t *gzip_tallies;    /* [n][CHN_GZIP_TALLY_WORDS] when the batch asked for them (may be NULL otherwise) */
 } chn_result;
 
 /* Up to TWO batches may be in flight per stream (submit, submit, wait, submit, wait, ...): batch i's count and

@@ -384,3 +384,72 @@ def test_cli_classify_gamma_beta(tmp_path, oracle_lib):
         assert rc == 0, err
         assert_same_tsv(out, want)
     oidx.free()
+
+
+def test_cli_gzip_column_from_device_tallies(tmp_path, oracle_lib):
+    """the `compression` column (src/utils.cpp:114-124): by default the deflate pass runs on the GPU (k_gzip_tally: zlib's level-6
+    deflate_slow as code-frequency tallies, sized on the host by _tr_flush_block's arithmetic); it must print exactly what the
+    host emulator (CHARON_GZIP_ON_HOST=1) and zlib itself (CHARON_ZLIB_ONLY=1) print, for every shape of read: random, N-rich,
+    tandem repeats, internal copies (long matches, lazy evaluation), homopolymers, short reads, reads beyond the device's length
+    limit and beyond one deflate block (both sized on the host), pairs (the two mates are compressed as ONE string)."""
+    r = np.random.default_rng(55)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    g0 = util.random_seq(util.rng(1), 6000)
+    for i, g in enumerate((g0, util.random_seq(util.rng(2), 6000))):
+        with open(tmp_path / ("g%d.fa" % i), "w") as f:
+            f.write(">g%d\n%s\n" % (i, g.decode()))
+    oidx = oracle_lib.Index.from_fasta([(str(tmp_path / "g0.fa"), "human"), (str(tmp_path / "g1.fa"), "microbial")], ["microbial", "human"])
+    oidx.store(str(tmp_path / "z.idx"))
+    oidx.free()
+    recs = []
+    lengths = [1, 2, 3, 4, 5, 7, 19, 41, 150, 300, 1000, 5000, 5000, 5000, 9000, 16383, 16384, 16385, 20000, 33000, 70000]
+    for i in range(420):
+        L = int(lengths[i % len(lengths)]) if i % 3 else int(r.integers(1, 4000))
+        s = acgt[r.integers(0, 4, L)].copy()
+        kind = i % 7
+        if kind == 1:
+            s[r.random(L) < 0.04] = ord("N")
+        elif kind == 2 and L > 20:
+            s = np.resize(acgt[r.integers(0, 4, int(r.integers(1, 9)))], L)          # tandem repeat
+        elif kind == 3 and L > 200:
+            for _ in range(12):                                                          # internal copies
+                a, b, ln = int(r.integers(0, L)), int(r.integers(0, L)), int(r.integers(10, 600))
+                ln = min(ln, L - a, L - b)
+                s[b:b + ln] = s[a:a + ln].copy()
+        elif kind == 4:
+            s[:] = acgt[int(r.integers(0, 4))]                                           # homopolymer
+        elif kind == 5 and L > 40:
+            s[L // 2:] = s[:L - L // 2].copy()                                           # one long repeat
+        elif kind == 6 and L > 3000:
+            s = np.resize(acgt[r.integers(0, 4, 3)], L)                                  # period-3 repeat: > 16 383 symbols? no: long matches
+        recs.append(bytes(s))
+    with open(tmp_path / "z.fasta", "w") as f:
+        for i, s in enumerate(recs):
+            f.write(">z%d\n%s\n" % (i, s.decode()))
+    args = ["--db", str(tmp_path / "z.idx"), "--min_quality", "0", str(tmp_path / "z.fasta")]
+    outs = {}
+    for mode, env in (("gpu", {}), ("host", {"CHARON_GZIP_ON_HOST": "1"}), ("zlib", {"CHARON_ZLIB_ONLY": "1"})):
+        rc, out, err = run_cli(args, str(tmp_path), dict(env, CHARON_BATCH_READS="100"))
+        assert rc == 0, err
+        outs[mode] = out
+    assert outs["gpu"] == outs["zlib"] == outs["host"]
+    # ... and the device really did the work: everything up to 16 384 letters that fits one deflate block (the last run was the zlib one,
+    # so look at the log of a fresh default run)
+    rc, out, err = run_cli(args, str(tmp_path))
+    import re
+    mm = re.search(r"gzip column: (\d+) reads sized from device deflate tallies", open(tmp_path / "charon.log").read())
+    n_dev = sum(1 for s in recs[1:] if len(s) <= 16384)  # (the dropped first read is tallied too, but harmlessly)
+    assert mm and n_dev - 5 <= int(mm.group(1)) <= n_dev + 1
+    assert len(outs["gpu"].strip().split("\n")) == len(recs) - 1
+    # classify gates on the column (min_compression 0.15): low-complexity reads lose their call in every mode alike
+    # pairs: both mates in one gzip member
+    m1, m2 = recs[10:130], recs[200:320]
+    for name, mates, tag in (("q_1.fasta", m1, "/1"), ("q_2.fasta", m2, "/2")):
+        with open(tmp_path / name, "w") as f:
+            for i, s in enumerate(mates):
+                f.write(">q%d%s\n%s\n" % (i, tag, s.decode()))
+    pargs = ["--db", str(tmp_path / "z.idx"), "--min_quality", "0", str(tmp_path / "q_1.fasta"), str(tmp_path / "q_2.fasta")]
+    a = run_cli(pargs, str(tmp_path), sub="classify")
+    b = run_cli(pargs, str(tmp_path), {"CHARON_ZLIB_ONLY": "1"}, sub="classify")
+    assert a[0] == 0 and b[0] == 0 and a[1] == b[1] and a[1].count("\n") == len(m1) - 1
+    assert any(ln.startswith("U") for ln in a[1].split("\n")) and any(ln.startswith("C") for ln in a[1].split("\n"))

@@ -737,3 +737,39 @@ def test_gamma_and_beta_models_call_category(api, oracle_lib):
         util.assert_parity(gpu, orc)
     g.destroy(); g2.destroy()
     oidx.free(); oidx2.free()
+
+
+def test_gzip_tallies_through_the_abi(api, oracle_lib):
+    """chn_batch.gzip_tallies: per read the literal/length and distance code frequencies of zlib's level-6 deflate block (the CLI
+    turns them into the exact gzip size; tests/test_gpu_cli.py compares that column with zlib itself on hundreds of shapes).
+    Here: the ABI plumbing and the invariants any correct tally has."""
+    from charon_amd import pack
+    r = util.rng(66)
+    gs = [util.random_seq(r, 4000), util.random_seq(r, 4000)]
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [0, 1], ["host", "microbial"])
+    g = util.gpu_index_from_oracle(api, oidx)
+    reads = [b"A", b"ACGTN", b"A" * 1000, b"ACGT" * 500, util.random_seq(r, 3000), util.random_seq(r, 9000), util.random_seq(r, 17000), gs[0][:700] * 3]
+    p = pack.pack_reads(reads)
+    st = api.Stream(g, len(reads), p["n_bases"])
+    st.set_model(api.default_model(2, 0, min_compression=0.9))  # a gate that every read would fail ...
+    st.submit_host(p, np.full(len(reads), 40.0, np.float32), None, gzip_tallies=16384)
+    out = st.wait_host()
+    t = out["gzip_tallies"].astype(np.int64)
+    lit, lens, dist, status = t[:, :256], t[:, 257:286], t[:, 286:316], t[:, 316]
+    assert [int(x != 0) for x in status] == [0, 0, 0, 0, 0, 0, 1, 0]  # 17 000 letters: beyond the device's bound -> sized on the host
+    ok = status == 0
+    assert (lens.sum(1) == dist.sum(1))[ok].all()               # every match has one length and one distance code
+    assert (lit[:, [65, 67, 71, 84, 78]].sum(1) == lit.sum(1))[ok].all()  # only A C G T N literals
+    assert lit[0, 65] == 1 and lens[0].sum() == 0
+    assert lit[1].sum() == 5 and lens[1].sum() == 0
+    assert lit[2, 65] >= 1 and lens[2, 28] >= 3                  # a homopolymer: one literal, then maximal (258) matches at distance 1
+    assert dist[2, 0] == lens[2].sum()
+    for i in (4, 5):                                            # random four-letter sequence: nearly everything is a short match
+        n = len(reads[i])
+        assert 0 < lit[i].sum() < 0.3 * n and lens[i, :10].sum() >= 0.9 * lens[i].sum() and lit[i].sum() + 3 * lens[i].sum() <= n
+    assert lit[7].sum() < 900 and lens[7, 28] >= 4              # a threefold repeat: the 2nd and 3rd copy are long matches
+    # ... is left open by the call kernel when the ratios are still to come (the caller applies it): calls survive
+    assert out["call"][7] == 0  # the repeat of the host genome is called although 0 < min_compression 0.9
+    st.destroy()
+    g.destroy()
+    oidx.free()
