@@ -18,7 +18,9 @@
 #include <algorithm>
 #include <cerrno>
 #include <climits>
+#include <chrono>
 #include <condition_variable>
+#include <functional>
 #include <deque>
 #include <mutex>
 #include <thread>
