@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <functional>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>

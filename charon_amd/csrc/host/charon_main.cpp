@@ -47,6 +47,9 @@
 #include <vector>
 
 #include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #ifdef _OPENMP
 #include <omp.h>
 #endif

@@ -4,7 +4,7 @@
 Builds a 2-category index file with the oracle's writer (test infrastructure used only to FABRICATE the input file),
 writes N synthetic 5 kb reads as FASTQ, then times the CLI at several -t values.  The CLI is expected to be bound by the
 host-side columns of the reference (per-read gzip ratio, FASTQ parsing, TSV printing), not by the GPU.
-usage: python tools/cli_throughput.py [n_reads] [workdir]
+usage: python tools/cli_throughput.py [n_reads] [workdir] [--gen-only]      (--gen-only: write bench.idx / reads.fastq and stop)
 """
 import os
 import subprocess
@@ -20,8 +20,10 @@ from tests import util  # noqa: E402
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
-    work = sys.argv[2] if len(sys.argv) > 2 else "/tmp/charon_cli_bench"
+    gen_only = "--gen-only" in sys.argv
+    argv = [a for a in sys.argv if a != "--gen-only"]
+    n = int(argv[1]) if len(argv) > 1 else 50000
+    work = argv[2] if len(argv) > 2 else "/tmp/charon_cli_bench"
     os.makedirs(work, exist_ok=True)
     r = util.rng(1)
     gs = [util.random_seq(r, 2_000_000), util.random_seq(r, 2_000_000)]
@@ -39,9 +41,11 @@ def main():
             s = int(r.integers(0, len(g) - 5000))
             f.write(b"@r%d\n%s\n+\n%s\n" % (i, util.mutate(r, g[s:s + 5000], 0.05), qual))
     print("fastq: %d reads, %.2f GB, written in %.1fs" % (n, os.path.getsize(fq) / 1e9, time.time() - t0), flush=True)
+    if gen_only:
+        return
     exe = os.path.join(ROOT, "charon_amd", "bin", "charon")
     ref = None
-    for label, extra in (("gzip column by the size emulator (default)", {}), ("gzip column by zlib (CHARON_ZLIB_ONLY=1)", {"CHARON_ZLIB_ONLY": "1"}),
+    for label, extra in (("gzip column: deflate tallies on the GPU (default)", {}), ("gzip column by zlib (CHARON_ZLIB_ONLY=1)", {"CHARON_ZLIB_ONLY": "1"}),
                          ("no gzip column (CHARON_SKIP_COMPRESSION=1)", {"CHARON_SKIP_COMPRESSION": "1"})):
         print(label, flush=True)
         for t in (1, 16, 64):
