@@ -308,8 +308,9 @@ def main():
 
     pcie_rate = None
     if not args.no_pcie and world == 1 and not paired and not rows_mode and not sparse_mode:
-        # host-buffer entry: packed batch in PINNED host memory (chn_host_alloc), two batches in flight, so the upload of batch
-        # i+1 (copy stream) overlaps the kernels of batch i; results come back into ordinary numpy arrays
+        # host-buffer entry: packed batch in PINNED host memory (chn_host_alloc), three batches in flight, so the upload of batch
+        # i+2 (copy stream) runs under the probe kernel of batch i+1 while batch i's count / model+call kernels finish beside it;
+        # results are downloaded in stream and come back into ordinary numpy arrays
         reads = last_reads
 
         def pinned_copy(dev_ptr, count, dtype):
@@ -325,11 +326,12 @@ def main():
         cph[:] = 0.3
         stream.submit_host(packed, mqh, cph)
         stream.wait_host()
-        k_pcie = 4
+        k_pcie = 10
         t1 = time.perf_counter()
         stream.submit_host(packed, mqh, cph)
+        stream.submit_host(packed, mqh, cph)
         for i in range(k_pcie):
-            if i + 1 < k_pcie:
+            if i + 2 < k_pcie:
                 stream.submit_host(packed, mqh, cph)
             stream.wait_host()
         pcie_rate = k_pcie * n_reads / (time.perf_counter() - t1)

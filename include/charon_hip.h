@@ -204,9 +204,12 @@ typedef struct chn_result {
     uint16_t *gzip_tallies;    /* [n][CHN_GZIP_TALLY_WORDS] when the batch asked for them (may be NULL otherwise) */
 } chn_result;
 
-/* Up to TWO batches may be in flight per stream (submit, submit, wait, submit, wait, ...): batch i's count and
- * model+call kernels run on a side HIP stream and overlap batch i+1's minimise+probe kernel.  chn_batch_wait returns
- * the OLDEST batch in flight.  With on_device results the returned pointers stay valid until the second-next submit.
+/* Up to THREE batches may be in flight per stream.  Two (submit, submit, wait, submit, wait, ...) let batch i's count and
+ * model+call kernels run on a side HIP stream under batch i+1's minimise+probe kernel; they then usually finish only when
+ * that kernel does, so a caller with HOST buffers keeps three in flight (submit i+2 before waiting for i): the upload of batch
+ * i+2 then runs under the probe kernel of batch i+1.  chn_batch_wait returns the OLDEST batch in flight.  With on_device
+ * results the returned pointers stay valid until the third-next submit.  Host results are downloaded in stream into
+ * page-locked staging right behind the kernels that produce them; chn_batch_wait copies from there.
  * Scratch: the per-batch row log is sized for twice the minimiser density of random sequence (not for the worst case
  * of one minimiser per base); a batch that overruns it is detected on the device and re-run by chn_batch_wait on
  * worst-case buffers allocated at that point (CHN_E_NOMEM if they do not fit) -- results are identical either way.
@@ -304,7 +307,7 @@ int chn_synth_reads(int device, uint64_t seed, const uint32_t *dev_genomes, uint
                     uint64_t first_read_id, uint64_t n_reads, uint32_t read_len_min, uint32_t read_len_max, double sub_rate,
                     double random_fraction, float mean_quality, chn_synth_reads_out *out);
 /* Page-locked host memory.  Host batches whose arrays live in such memory are uploaded asynchronously on a copy stream,
- * so with two batches in flight the upload of batch i+1 overlaps the kernels of batch i; pageable memory works too but
+ * so with batches in flight the upload of the next one overlaps the kernels of those before; pageable memory works too but
  * its copies are staged synchronously by the runtime. */
 int chn_host_alloc(uint64_t bytes, void **ptr);
 int chn_host_free(void *ptr);

@@ -773,3 +773,35 @@ def test_gzip_tallies_through_the_abi(api, oracle_lib):
     st.destroy()
     g.destroy()
     oidx.free()
+
+
+def test_three_batches_in_flight_come_back_in_order(api, oracle_lib):
+    """Up to three batches may be in flight (a caller with host buffers keeps the next upload under the running probe kernel);
+    chn_batch_wait hands them back oldest first, each equal to the same batch run alone; a fourth submit is refused."""
+    from charon_amd import pack
+    r = util.rng(91)
+    gs = [util.random_seq(r, 30000), util.random_seq(r, 30000)]
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [0, 1], ["host", "microbial"])
+    g = util.gpu_index_from_oracle(api, oidx)
+    sets = [util.sample_reads(r, gs, n, (150, 3000), sub_rate=0.04) for n in (700, 1100, 400, 900, 650)]
+    alone = [run_gpu(api, g, s, comp=0.0) for s in sets]
+    packed = [pack.pack_reads(s) for s in sets]
+    cap = max(len(s) for s in sets)
+    st = api.Stream(g, cap, max(p["n_bases"] for p in packed))
+    st.set_model(api.default_model(2, 0))
+    sub = lambda i: st.submit_host(packed[i], np.full(len(sets[i]), 40.0, np.float32), np.zeros(len(sets[i]), np.float32))
+    sub(0); sub(1); sub(2)
+    with pytest.raises(RuntimeError, match="in flight"):
+        sub(3)
+    got = [st.wait_host()]
+    sub(3)
+    got.append(st.wait_host())
+    sub(4)
+    got += [st.wait_host(), st.wait_host(), st.wait_host()]
+    for a, b in zip(alone, got):
+        for key in ("num_hashes", "counts", "unique", "call", "conf"):
+            assert np.array_equal(a[key], b[key]), key
+        assert np.array_equal(a["probs"], b["probs"], equal_nan=True)
+    st.destroy()
+    g.destroy()
+    oidx.free()
