@@ -91,6 +91,7 @@ int main(int argc, char **argv) {
     if (sub == "_gzsize") {  // hidden diagnostic: per record, gzip size by the linked zlib and by the size emulator (no GPU involved)
         try {
             if (argc < 3) return 2;
+            if (const char *t = std::getenv("CHARON_READER_THREADS")) g_reader_threads = std::max(1, std::atoi(t));
             BlockReader in(argv[2]);
             RawBlock blk;
             Deflater d;

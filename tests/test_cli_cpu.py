@@ -170,3 +170,50 @@ def test_truncated_or_corrupt_gz_input_is_an_error(tmp_path):
     empty = tmp_path / "empty.fastq"
     empty.write_bytes(b"")
     assert run(["_records", str(empty)])[0] == 0
+
+
+def _bgzf(data, block=65280, level=6, eof_marker=True):
+    """BGZF writer (SAM specification 4.1): gzip members of at most 64 KiB with their size in a 'BC' extra subfield"""
+    import struct, zlib
+    out = bytearray()
+    chunks = [data[i:i + block] for i in range(0, len(data), block)] + ([b""] if eof_marker else [])
+    for c in chunks:
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        z = co.compress(c) + co.flush()
+        bsize = 12 + 6 + len(z) + 8 - 1
+        out += b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize)
+        out += z + struct.pack("<II", zlib.crc32(c) & 0xFFFFFFFF, len(c))
+    return bytes(out)
+
+
+def test_bgzf_input_is_inflated_member_by_member_in_parallel(tmp_path):
+    """BGZF read files (bgzip / htslib / BCL Convert) are gzip members with known sizes: the reader inflates them in parallel
+    (the reference's seqan3 bgzf stream does) and must see exactly the records zlib's single stream sees"""
+    import gzip
+    data = gzip.decompress(open(os.path.join(G, "cfg1_reads.fastq.gz"), "rb").read())
+    big = data * 40  # 8000 records, several hundred members at the small block size
+    plain = tmp_path / "big.fastq"
+    plain.write_bytes(big)
+    want = subprocess.run([EXE, "_records", str(plain)], stdout=subprocess.PIPE).stdout
+    assert want.count(b"\n") == 8000
+    for block, threads, max_bytes in ((65280, 8, 1 << 20), (1000, 3, 4096), (1, 2, 64), (65280, 1, 1 << 26)):
+        src = big if block > 1 else b"".join(data.splitlines(keepends=True)[:20])  # one-byte members: five records
+        f = tmp_path / ("b%d.fastq.gz" % block)
+        f.write_bytes(_bgzf(src, block))
+        env = dict(os.environ, CHARON_READER_THREADS=str(threads))
+        got = subprocess.run([EXE, "_records", str(f), "1000", str(max_bytes)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        ref = subprocess.run([EXE, "_records", str(f), "1000", str(max_bytes)], stdout=subprocess.PIPE, env=dict(env, CHARON_NO_BGZF="1"))
+        assert got.returncode == 0, got.stderr
+        assert got.stdout == ref.stdout
+        if block > 1:
+            assert got.stdout == want
+    # damage: a flipped data byte (CRC32), a cut-off file, a member that is not BGZF in the middle
+    good = _bgzf(big, 65280)
+    bad = bytearray(good); bad[len(bad) // 2] ^= 0x11
+    cut = good[:len(good) * 2 // 3]
+    mixed = _bgzf(data, 65280, eof_marker=False) + gzip.compress(data)
+    for name, blob in (("crc", bytes(bad)), ("cut", cut), ("mixed", mixed)):
+        f = tmp_path / (name + ".fastq.gz")
+        f.write_bytes(blob)
+        rc, out, err = run(["_records", str(f)])
+        assert rc != 0 and "gzip read error" in err, (name, rc, err)
