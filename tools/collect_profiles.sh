@@ -64,3 +64,11 @@ for f in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
     except Exception as e:
         print(os.path.basename(f), "failed", e)
 PY
+# 6. the CLI: phase timers + per-kernel GPU time of one run, throughput table, compressed inputs
+bash $ROOT/tools/cli_phase_run.sh 400000 > /dev/null 2>&1 || true
+cp $ROOT/gpurun_out/cli_phase/phase.txt $OUT/cli_phase.txt 2>/dev/null || true
+cp $ROOT/gpurun_out/cli_phase/kernel_stats_cli.csv $OUT/kernel_stats_cli.csv 2>/dev/null || true
+python3 $ROOT/tools/cli_throughput.py 400000 /tmp/clib > $OUT/cli_throughput_raw.txt 2>&1 || true
+bash $ROOT/tools/cli_gz_run.sh 100000 > /dev/null 2>&1 || true
+cp $ROOT/gpurun_out/cli_gz.txt $OUT/cli_gz.txt 2>/dev/null || true
+./tools/h2d_bench > $OUT/h2d_microbench.txt 2>&1 || true
