@@ -70,6 +70,7 @@ bool g_gzip_emulator = true;
 #include "log_util.inc"
 #include "dehost_args.inc"
 #include "index_file.inc"
+#include "inflate_stream.inc"
 #include "fastx_reader.inc"
 #include "result.inc"
 #include "dehost.inc"
@@ -77,6 +78,7 @@ bool g_gzip_emulator = true;
 
 }  // namespace
 
+std::string g_inflate_stats;
 int main(int argc, char **argv) {
     if (argc < 2) { std::cerr << "A subcommand is required\nRun with --help for more information.\n"; return 106; }
     const std::string sub = argv[1];
@@ -105,6 +107,54 @@ int main(int argc, char **argv) {
                     std::cout << std::string(r.id, r.id_len) << "\t" << d.zlib_size(n) << "\t" << e << "\n";
                 }
             return 0;
+        } catch (std::exception &e) { std::cerr << "charon: " << e.what() << std::endl; return 1; }
+    }
+    if (sub == "_inflate") {  // hidden diagnostic: inflate a .gz with this build's decoder and with zlib; sizes, checksums, rates
+        try {
+            if (argc < 3) return 2;
+            if (const char *t = std::getenv("CHARON_READER_THREADS")) g_reader_threads = std::max(1, std::atoi(t));
+            auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+            const size_t piece = argc > 3 ? (size_t)std::atol(argv[3]) : ((size_t)64 << 20);
+            unsigned long long total = 0, sum = 1469598103934665603ULL;
+            double t0 = now();
+            {
+                FastInflate fi(argv[2]);
+                if (!fi.open()) { std::cerr << "charon: not a mappable gzip file\n"; return 1; }
+                std::vector<char> buf;
+                while (!fi.at_end()) {
+                    buf.clear();
+                    fi.fill(buf, piece);
+                    total += buf.size();
+                    if (!std::getenv("CHARON_DIAG_NO_CRC")) sum ^= (unsigned long long)crc32(0L, reinterpret_cast<const unsigned char *>(buf.data()), (uInt)buf.size()) + total;
+                    sum *= 1099511628211ULL;
+                }
+                g_inflate_stats = std::to_string(fi.parallel_rounds()) + " rounds, " + std::to_string(fi.chunks_accepted()) + " chunks counted, " + std::to_string(fi.chunks_discarded()) + " discarded";
+            }
+            const double t_own = now() - t0;
+            std::cout << "parallel: " << g_inflate_stats << "\n";
+            unsigned long long ztotal = 0, zsum = 1469598103934665603ULL;
+            t0 = now();
+            if (!std::getenv("CHARON_SKIP_ZLIB")) {
+                gzFile f = gzopen(argv[2], "rb");
+                if (!f) return 1;
+                gzbuffer(f, 1 << 20);
+                std::vector<char> buf(piece + 65536 + 400);
+                // the same piece boundaries cannot be reproduced through gzread, so the checksum is over the whole data via one running crc
+                unsigned long zc = crc32(0L, Z_NULL, 0);
+                for (;;) {
+                    const int n = gzread(f, buf.data(), (unsigned)std::min<size_t>(buf.size(), 1u << 30));
+                    if (n <= 0) break;
+                    ztotal += (unsigned long long)n;
+                    if (!std::getenv("CHARON_DIAG_NO_CRC")) zc = crc32(zc, reinterpret_cast<const unsigned char *>(buf.data()), (uInt)n);
+                }
+                gzclose(f);
+                zsum = zc;
+            }
+            const double t_z = now() - t0;
+            std::cout << "own: " << total << " bytes in " << t_own << " s (" << total / t_own / 1e9 << " GB/s)  zlib: " << ztotal << " bytes in " << t_z << " s ("
+                      << ztotal / std::max(t_z, 1e-9) / 1e9 << " GB/s)\n";
+            (void)sum; (void)zsum;
+            return total == ztotal || std::getenv("CHARON_SKIP_ZLIB") ? 0 : 3;
         } catch (std::exception &e) { std::cerr << "charon: " << e.what() << std::endl; return 1; }
     }
     if (sub == "_records") {  // hidden diagnostic: dump what the block reader sees (no GPU involved)

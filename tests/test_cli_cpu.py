@@ -217,3 +217,100 @@ def test_bgzf_input_is_inflated_member_by_member_in_parallel(tmp_path):
         f.write_bytes(blob)
         rc, out, err = run(["_records", str(f)])
         assert rc != 0 and "gzip read error" in err, (name, rc, err)
+
+
+def _fastq_blob(n, seed, lens=(80, 150, 300, 5000)):
+    import random
+    rnd = random.Random(seed)
+    out = []
+    for i in range(n):
+        L = rnd.choice(lens)
+        seq = "".join(rnd.choice("ACGTN" if rnd.random() < 0.02 else "ACGT") for _ in range(L))
+        q, cur = [], rnd.choice("#+5?I")
+        while sum(map(len, q)) < L:
+            q.append(cur * rnd.randint(1, 40))
+            cur = rnd.choice("+5?II??5")
+        out.append("@read%d runid=%08x ch=%d\n%s\n+\n%s\n" % (i, rnd.getrandbits(32), rnd.randint(1, 512), seq, "".join(q)[:L]))
+    return "".join(out).encode()
+
+
+def _records_of(path, env=None, args=("300", "65536")):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([EXE, "_records", str(path)] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+    return p.returncode, p.stdout, p.stderr.decode(errors="replace")
+
+
+def test_one_stream_gz_decoded_in_chunks_equals_zlib(tmp_path):
+    """A one-stream .gz is cut at searched block starts and decoded by several threads with markers for the unknown window
+    (charon_amd/csrc/host/inflate_stream.inc); whatever the chunking, the records must be the ones zlib's inflate gives."""
+    import gzip, zlib
+    blob = _fastq_blob(3000, 11)
+    cut = lambda n: blob.rfind(b"\n@read", 0, n) + 1  # a record boundary at or before n
+    a, b, c = cut(300000), cut(400000), cut(900000)
+    cases = {}
+    for lvl in (1, 6, 9):
+        cases["l%d" % lvl] = gzip.compress(blob, lvl)
+    cases["stored"] = gzip.compress(blob[:a], 0)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31, 8, zlib.Z_FIXED)
+    cases["fixed"] = co.compress(blob[:a]) + co.flush()
+    cases["members"] = gzip.compress(blob[:b], 6) + gzip.compress(blob[b:c], 1) + gzip.compress(blob[c:], 9)
+    # header with FEXTRA, FNAME, FCOMMENT, FHCRC; trailing bytes that are not a gzip header
+    raw = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = raw.compress(blob) + raw.flush()
+    import struct
+    hdr = b"\x1f\x8b\x08\x1e\0\0\0\0\0\x03" + struct.pack("<H", 5) + b"ab\x01\x00z" + b"reads.fastq\0" + b"a comment\0"
+    hdr += struct.pack("<H", zlib.crc32(hdr) & 0xFFFF)
+    cases["header"] = hdr + body + struct.pack("<II", zlib.crc32(blob) & 0xFFFFFFFF, len(blob) & 0xFFFFFFFF) + b"\0\0\0trailing"
+    # full flushes: byte-aligned empty stored blocks between dynamic ones
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    parts = []
+    for i in range(0, len(blob), 150000):
+        parts.append(co.compress(blob[i:i + 150000]) + co.flush(zlib.Z_FULL_FLUSH if (i // 150000) % 2 else zlib.Z_SYNC_FLUSH))
+    cases["flushes"] = b"".join(parts) + co.flush()
+    for name, data in cases.items():
+        f = tmp_path / (name + ".fastq.gz")
+        f.write_bytes(data)
+        rc0, want, err0 = _records_of(f, {"CHARON_ZLIB_INFLATE": "1"})
+        assert rc0 == 0 and want.count(b"\n") > 100, (name, err0)
+        for threads, chunk in ((1, 0), (2, 4096), (3, 20000), (8, 65536), (4, 1024)):
+            env = {"CHARON_READER_THREADS": str(threads)}
+            if chunk:
+                env["CHARON_INFLATE_CHUNK"] = str(chunk)
+            rc, got, err = _records_of(f, env)
+            assert rc == 0, (name, threads, chunk, err)
+            assert got == want, (name, threads, chunk)
+    # the parallel path really ran (and counted its chunks) on the level-6 file
+    p = subprocess.run([EXE, "_inflate", str(tmp_path / "l6.fastq.gz")], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, CHARON_READER_THREADS="4", CHARON_INFLATE_CHUNK="30000"))
+    assert p.returncode == 0, p.stderr
+    rounds = int(p.stdout.decode().split("parallel:")[1].split()[0])
+    assert rounds >= 2, p.stdout
+
+
+def test_damaged_gz_fails_like_zlib_never_crashes(tmp_path):
+    """bit flips and cuts anywhere in a .gz: this build's decoder (sequential and chunked) must fail where zlib fails and give
+    zlib's records where zlib succeeds (a flip in the header's mtime, say) -- and never die on a signal"""
+    import gzip, random
+    rnd = random.Random(5)
+    blob = _fastq_blob(400, 3, lens=(80, 150, 300))
+    good = gzip.compress(blob, 6)
+    f = tmp_path / "d.fastq.gz"
+    for trial in range(120):
+        b = bytearray(good)
+        kind = trial % 3
+        if kind == 0:
+            p = rnd.randrange(len(b)); b[p] ^= 1 << rnd.randrange(8)
+        elif kind == 1:
+            b = b[:rnd.randrange(1, len(b))]
+        else:
+            p = rnd.randrange(len(b) - 8); b[p:p + rnd.randint(1, 8)] = bytes(rnd.randrange(256) for _ in range(rnd.randint(1, 8)))
+        f.write_bytes(bytes(b))
+        rc0, want, _ = _records_of(f, {"CHARON_ZLIB_INFLATE": "1"})
+        for env in ({"CHARON_READER_THREADS": "1"}, {"CHARON_READER_THREADS": "4", "CHARON_INFLATE_CHUNK": "2048"}):
+            rc, got, err = _records_of(f, env)
+            assert rc in (0, 1), (trial, rc, err)
+            if rc0 == 0:
+                assert rc == 0 and got == want, (trial, kind, err)
+            else:
+                assert rc == 1 and ("gzip read error" in err or "parse error" in err), (trial, kind, err)
