@@ -16,7 +16,7 @@ for f in reads.fastq plain.fastq.gz blocked.fastq.gz; do
     CHARON_TIMING=1 $EXE dehost --db $W/bench.idx -t $t --log $W/c.log $W/$f > $W/out_$f.tsv 2> $W/err.txt
     e=$(date +%s.%N)
     python3 -c "print('$f -t $t: %.3f s -> %.0f reads/s' % ($e - $s, $N / ($e - $s)))" >> $OUT
-    grep "main thread" $W/err.txt >> $OUT
+    grep "main thread\|reader thread" $W/err.txt >> $OUT
   done
 done
 cmp $W/out_reads.fastq.tsv $W/out_plain.fastq.gz.tsv && cmp $W/out_reads.fastq.tsv $W/out_blocked.fastq.gz.tsv && echo "TSV identical for the three inputs" >> $OUT
