@@ -60,6 +60,16 @@ def test_cli_golden_cfg1(tmp_path):
     # small GPU batches, more host threads: identical rows
     rc, out2, err = run_cli(["--db", os.path.join(G, "cfg1.idx"), "-t", "4", fq], str(tmp_path), {"CHARON_BATCH_READS": "37"})
     assert rc == 0 and out2 == out
+    # the same reads as a one-stream .gz cut into chunks (this build's inflate, several threads), as BGZF, through zlib, and as plain text
+    import subprocess, sys
+    data = gzip.decompress(open(fq, "rb").read())
+    (tmp_path / "plain.fastq").write_bytes(data)
+    subprocess.run([sys.executable, os.path.join(util.ROOT, "tools", "make_bgzf.py"), str(tmp_path / "plain.fastq"), str(tmp_path / "b.fastq.gz"), "6", "2"], check=True)
+    (tmp_path / "l1.fastq.gz").write_bytes(gzip.compress(data, 1))
+    for f, env in ((fq, {"CHARON_INFLATE_CHUNK": "2048"}), (str(tmp_path / "l1.fastq.gz"), {"CHARON_INFLATE_CHUNK": "4096"}),
+                   (str(tmp_path / "b.fastq.gz"), {}), (fq, {"CHARON_ZLIB_INFLATE": "1"}), (str(tmp_path / "plain.fastq"), {})):
+        rc, o, err = run_cli(["--db", os.path.join(G, "cfg1.idx"), "-t", "4", f], str(tmp_path), env)
+        assert rc == 0 and o == out, (f, env, err)
     # --extract drives the training cache (num_reads_to_fit 20 -> models retrain, cached reads re-classified)
     rc, out3, err = run_cli(["--db", os.path.join(G, "cfg1.idx"), "--extract", "microbial", "--num_reads_to_fit", "20", fq], str(tmp_path),
                             {"CHARON_BATCH_READS": "64"})
