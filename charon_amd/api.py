@@ -46,13 +46,13 @@ class Batch(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("on_device", C.c_uint32), ("n_reads", C.c_uint64), ("n_bases", C.c_uint64),
                 ("bases2", C.c_void_p), ("nmask", C.c_void_p), ("seg1_offset", C.c_void_p), ("seg1_length", C.c_void_p),
                 ("seg2_offset", C.c_void_p), ("seg2_length", C.c_void_p), ("mean_quality", C.c_void_p),
-                ("compression", C.c_void_p), ("gzip_tallies", C.c_uint32), ("reserved1", C.c_uint32)]
+                ("compression", C.c_void_p), ("gzip_tallies", C.c_uint32), ("gzip_output", C.c_uint32)]
 
 
 class Result(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("on_device", C.c_uint32), ("num_hashes", C.c_void_p), ("counts", C.c_void_p),
                 ("unique_counts", C.c_void_p), ("probabilities", C.c_void_p), ("call", C.c_void_p), ("confidence", C.c_void_p),
-                ("flags", C.c_void_p), ("gzip_tallies", C.c_void_p)]
+                ("flags", C.c_void_p), ("gzip_tallies", C.c_void_p), ("gzip_sizes", C.c_void_p)]
 
 
 class SynthReadsOut(C.Structure):
@@ -256,12 +256,13 @@ class Stream:
     def set_model(self, model):
         _chk(_L.chn_model_set(self.h, C.byref(model)))
 
-    def submit_host(self, packed, mean_quality=None, compression=None, gzip_tallies=0):
-        """packed: dict from charon_amd.pack.pack_reads; gzip_tallies: longest read to tally on the device (0 = off)"""
+    def submit_host(self, packed, mean_quality=None, compression=None, gzip_tallies=0, gzip_output=0):
+        """packed: dict from charon_amd.pack.pack_reads; gzip_tallies: longest read to tally on the device (0 = off);
+        gzip_output: 0 tallies, 1 gzip member sizes (tree arithmetic on the device as well), 2 both"""
         b, keep, n = self._host_batch(packed, mean_quality, compression)
-        b.gzip_tallies = gzip_tallies
+        b.gzip_tallies, b.gzip_output = gzip_tallies, gzip_output
         _chk(_L.chn_batch_submit(self.h, C.byref(b)))
-        self._fifo.append((n, keep, gzip_tallies))
+        self._fifo.append((n, keep, gzip_tallies, gzip_output))
 
     def _host_batch(self, packed, mean_quality, compression):
         n = len(packed["seg1_length"])
@@ -367,11 +368,15 @@ class Stream:
                    probs=np.zeros((n, Cn), np.float64), call=np.zeros(n, np.uint8), conf=np.zeros(n, np.uint8),
                    flags=np.zeros(n, np.uint8))
         want_gz = len(self._fifo[0]) > 2 and self._fifo[0][2]
-        if want_gz:
+        gz_out = self._fifo[0][3] if len(self._fifo[0]) > 3 else 0
+        if want_gz and gz_out != 1:
             out["gzip_tallies"] = np.zeros((n, 320), np.uint16)
+        if want_gz and gz_out != 0:
+            out["gzip_sizes"] = np.zeros(n, np.uint32)
         r = Result(C.sizeof(Result), 0, out["num_hashes"].ctypes.data, out["counts"].ctypes.data, out["unique"].ctypes.data,
                    out["probs"].ctypes.data, out["call"].ctypes.data, out["conf"].ctypes.data, out["flags"].ctypes.data,
-                   out["gzip_tallies"].ctypes.data if want_gz else None)
+                   out["gzip_tallies"].ctypes.data if "gzip_tallies" in out else None,
+                   out["gzip_sizes"].ctypes.data if "gzip_sizes" in out else None)
         _chk(_L.chn_batch_wait(self.h, C.byref(r)))
         self._fifo.pop(0)
         return out

@@ -48,6 +48,7 @@
 #include "parts/k3_model_call.inc"
 #include "parts/len_order.inc"
 #include "parts/gzip_tally.inc"
+#include "parts/gzip_size_dev.inc"
 #include "parts/ef_decode.inc"
 #include "parts/synth_kernels.inc"
 #include "parts/abi_index_model.inc"

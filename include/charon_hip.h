@@ -177,8 +177,14 @@ typedef struct chn_batch {
      * call kernel runs: its `compression < min_compression` gate (include/read_entry.hpp:189-191,250-252) is left open and the
      * CALLER must apply it (call = CHN_NO_CALL where the ratio is below the threshold). */
     uint32_t gzip_tallies;
-    uint32_t reserved1;
+    /* What comes back for the reads tallied on the device: CHN_GZIP_TALLIES (0) the tallies; CHN_GZIP_SIZES the gzip member
+     * SIZES (chn_result.gzip_sizes) -- _tr_flush_block's tree arithmetic then runs on the device too (k_gzip_size) and only
+     * four bytes per read are downloaded; CHN_GZIP_BOTH both. */
+    uint32_t gzip_output;
 } chn_batch;
+#define CHN_GZIP_TALLIES 0u
+#define CHN_GZIP_SIZES 1u
+#define CHN_GZIP_BOTH 2u
 #define CHN_GZIP_MAX_LEN 16384u
 #define CHN_GZIP_TALLY_WORDS 320u /* per read: [0,286) literal/length code frequencies, [286,316) distance code frequencies,
                                    * [316] status: 0 = tallies valid, non-zero = not handled on the device (longer than asked for,
@@ -202,6 +208,8 @@ typedef struct chn_result {
     uint8_t *confidence;       /* [n] */
     uint8_t *flags;            /* [n] */
     uint16_t *gzip_tallies;    /* [n][CHN_GZIP_TALLY_WORDS] when the batch asked for them (may be NULL otherwise) */
+    uint32_t *gzip_sizes;      /* [n] bytes of the gzip member (get_compression_ratio's numerator) when the batch asked for sizes;
+                                * 0 = not handled on the device (too long, more than one deflate block): size it on the host */
 } chn_result;
 
 /* Up to THREE batches may be in flight per stream.  Two (submit, submit, wait, submit, wait, ...) let batch i's count and

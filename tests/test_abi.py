@@ -24,7 +24,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(api.Model) == 104  # + dist, pos_params, neg_params (round 2)
     assert ctypes.sizeof(api.StreamCfg) == 24
     assert ctypes.sizeof(api.Batch) == 96  # + gzip_tallies (round 2)
-    assert ctypes.sizeof(api.Result) == 72  # + gzip_tallies (round 2)
+    assert ctypes.sizeof(api.Result) == 80  # + gzip_tallies, gzip_sizes (round 2)
 
 
 def test_default_model_is_reference_defaults():

@@ -805,3 +805,50 @@ def test_three_batches_in_flight_come_back_in_order(api, oracle_lib):
     st.destroy()
     g.destroy()
     oidx.free()
+
+
+def test_gzip_sizes_on_the_device_equal_zlib(api, oracle_lib):
+    """chn_batch.gzip_output = sizes: deflate pass AND _tr_flush_block's tree arithmetic on the device; the number that comes back
+    is the byte count of the gzip member zlib writes for the read's letters (level 6, as gzip-hpp does: src/utils.cpp:114-124),
+    for every shape of read -- stored, static and dynamic blocks, forced second code, bit-length overflow"""
+    import zlib
+    from charon_amd import pack
+    r = util.rng(67)
+    gs = [util.random_seq(r, 4000), util.random_seq(r, 4000)]
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [0, 1], ["host", "microbial"])
+    g = util.gpu_index_from_oracle(api, oidx)
+    reads = [b"A", b"AC", b"ACG", b"ACGTN", b"A" * 1000, b"ACGT" * 500, b"N" * 300, b"AAC" * 700, gs[0][:700] * 3, util.random_seq(r, 17000)]
+    for n in (4, 7, 10, 16, 33, 70, 150, 400, 1000, 2500, 5000, 9000, 16384):
+        reads.append(util.random_seq(r, n))
+        reads.append(bytes(r.choice(list(b"ACGTN"), n, p=[0.3, 0.2, 0.2, 0.2, 0.1]).astype(np.uint8)))
+    for k in range(60):  # low-entropy and skewed compositions: long codes, few symbols
+        n = int(r.integers(20, 6000))
+        p = r.dirichlet([0.3] * 4)
+        unit = bytes(r.choice(list(b"ACGT"), int(r.integers(1, 40)), p=p).astype(np.uint8))
+        s = bytearray((unit * (n // len(unit) + 1))[:n])
+        for _ in range(int(r.integers(0, 30))):
+            s[int(r.integers(0, n))] = b"ACGT"[int(r.integers(0, 4))]
+        reads.append(bytes(s))
+    p = pack.pack_reads(reads)
+    st = api.Stream(g, len(reads), p["n_bases"])
+    st.set_model(api.default_model(2, 0))
+    st.submit_host(p, np.full(len(reads), 40.0, np.float32), None, gzip_tallies=16384, gzip_output=2)
+    out = st.wait_host()
+    sizes, status = out["gzip_sizes"], out["gzip_tallies"][:, 316]
+
+    def zsize(b):
+        co = zlib.compressobj(6, zlib.DEFLATED, 31, 8)
+        return len(co.compress(b) + co.flush())
+    for i, rd in enumerate(reads):
+        if len(rd) > 16384:
+            assert status[i] != 0 and sizes[i] == 0
+            continue
+        assert status[i] == 0, i
+        assert int(sizes[i]) == zsize(rd), (i, len(rd), rd[:40])
+    # sizes only: no tallies come back, the same numbers do
+    st.submit_host(p, np.full(len(reads), 40.0, np.float32), None, gzip_tallies=16384, gzip_output=1)
+    out1 = st.wait_host()
+    assert "gzip_tallies" not in out1 and np.array_equal(out1["gzip_sizes"], sizes)
+    st.destroy()
+    g.destroy()
+    oidx.free()
