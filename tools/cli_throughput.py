@@ -1,9 +1,8 @@
 #!/usr/bin/env python3
 """End-to-end throughput of the drop-in CLI (charon_amd/bin/charon dehost) on a synthetic FASTQ file.
 
-Builds a 2-category index file with the oracle's writer (test infrastructure used only to FABRICATE the input file),
-writes N synthetic 5 kb reads as FASTQ, then times the CLI at several -t values.  The CLI is expected to be bound by the
-host-side columns of the reference (per-read gzip ratio, FASTQ parsing, TSV printing), not by the GPU.
+Writes two 2 Mb synthetic genomes, builds a 2-category index from them with this build's own `charon index`, writes N synthetic
+5 kb reads (mutated stretches of the genomes) as FASTQ, then times `charon dehost` at several -t values.
 usage: python tools/cli_throughput.py [n_reads] [workdir] [--gen-only]      (--gen-only: write bench.idx / reads.fastq and stop)
 """
 import os
@@ -15,8 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import pyoracle as po  # noqa: E402
-from tests import util  # noqa: E402
+from tests import util  # noqa: E402  (random_seq / mutate helpers only)
 
 
 def main():
@@ -28,10 +26,21 @@ def main():
     r = util.rng(1)
     gs = [util.random_seq(r, 2_000_000), util.random_seq(r, 2_000_000)]
     t0 = time.time()
-    idx = util.build_oracle_index(po, [[gs[0]], [gs[1]]], [0, 1], ["microbial", "human"])
-    idx.compress()
-    idx.store(os.path.join(work, "bench.idx"))
-    print("index: S=%d rows, built+stored in %.1fs" % (idx.bin_size, time.time() - t0), flush=True)
+    exe = os.path.join(ROOT, "charon_amd", "bin", "charon")
+    with open(os.path.join(work, "refs.tsv"), "w") as tab:
+        for name, g in (("microbial", gs[0]), ("human", gs[1])):
+            fa = os.path.join(work, name + ".fa")
+            with open(fa, "wb") as f:
+                f.write(b">" + name.encode() + b"\n" + g + b"\n")
+            tab.write("%s\t%s\n" % (fa, name))
+    for f in ("bench.idx",):
+        if os.path.exists(os.path.join(work, f)):
+            os.remove(os.path.join(work, f))
+    p = subprocess.run([exe, "index", "-p", os.path.join(work, "bench"), "--log", os.path.join(work, "i.log"), os.path.join(work, "refs.tsv")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if p.returncode or not os.path.exists(os.path.join(work, "bench.idx")):
+        sys.exit("charon index failed: " + p.stderr.decode()[-500:])
+    print("index: built by `charon index` in %.1fs" % (time.time() - t0), flush=True)
     fq = os.path.join(work, "reads.fastq")
     t0 = time.time()
     with open(fq, "wb") as f:
@@ -43,7 +52,6 @@ def main():
     print("fastq: %d reads, %.2f GB, written in %.1fs" % (n, os.path.getsize(fq) / 1e9, time.time() - t0), flush=True)
     if gen_only:
         return
-    exe = os.path.join(ROOT, "charon_amd", "bin", "charon")
     ref = None
     for label, extra in (("gzip column: deflate tallies on the GPU (default)", {}), ("gzip column by zlib (CHARON_ZLIB_ONLY=1)", {"CHARON_ZLIB_ONLY": "1"}),
                          ("no gzip column (CHARON_SKIP_COMPRESSION=1)", {"CHARON_SKIP_COMPRESSION": "1"})):
