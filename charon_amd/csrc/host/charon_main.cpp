@@ -16,6 +16,7 @@
 // `charon classify` (src/classify_main.cpp) shares the loop: call_category for every read, gamma / beta models (--dist), its own defaults.
 // Not implemented: .bz2 input.
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <climits>
 #include <chrono>
