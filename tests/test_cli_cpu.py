@@ -268,6 +268,9 @@ def test_one_stream_gz_decoded_in_chunks_equals_zlib(tmp_path):
     for i in range(0, len(blob), 150000):
         parts.append(co.compress(blob[i:i + 150000]) + co.flush(zlib.Z_FULL_FLUSH if (i // 150000) % 2 else zlib.Z_SYNC_FLUSH))
     cases["flushes"] = b"".join(parts) + co.flush()
+    # runs and short periods (matches at distance 1 .. 7, also across chunk starts), far more repetitive than the expansion cap allows
+    rep = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, (b"A" * 3000 + b"ACG" * 400 + b"AC" * 300)[:4000 + (i % 7)], b"I" * (4000 + (i % 7))) for i in range(400))
+    cases["runs"] = gzip.compress(rep, 6)
     for name, data in cases.items():
         f = tmp_path / (name + ".fastq.gz")
         f.write_bytes(data)
