@@ -338,6 +338,15 @@ def main():
         for a in (packed["bases2"], packed["seg1_offset"], packed["seg1_length"], mqh, cph):
             api.host_free(a)
 
+    # what the chip gives the bare probe pattern on this index, measured now (a few ms): the honest ceiling of the probe kernel
+    gather_roof = None
+    if not rows_mode and not sparse_mode:
+        k1_rate = (total_min * index.desc.hash_funs / (k1_ms / max(k1_n, 1) * 1e-3)) if k1_ms > 0 else 0.0
+        roof = {pol: index.gather_roof(nt=(pol == "nt")) for pol in ("default", "nt")}
+        best = max(roof.values())
+        gather_roof = {"default_policy_fetches_per_s": roof["default"], "nt_policy_fetches_per_s": roof["nt"],
+                       "kernel_frac_of_roof": (k1_rate / best) if best > 0 else None,
+                       "pattern": "independent uniformly random fetches of 8*W bytes, one per thread in flight, 32 wavefronts per CU"}
     out = None
     if rank == 0:
         k1_avg = k1_ms / max(k1_n, 1)
@@ -374,9 +383,10 @@ def main():
                          "traffic_source": traffic["source"] if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_avg,
                          "gathers_per_s": (total_min * index.desc.hash_funs / (k1_avg * 1e-3)) if k1_avg > 0 else 0.0,
+                         "gather_roof": gather_roof,
                          "note": "HBM-bound on random row probes: each probe uses 8*W bytes of a 128-byte line, so traffic/algorithmic ~ 8x is "
-                                 "line granularity, not re-reads; the measured pure-gather roof of this chip is 48.6e9 (default policy) to "
-                                 "54.3e9 (nt) gathers/s from a 39 GB table (profiles/r01/gather_microbench.txt, gather_policy_microbench.txt)",
+                                 "line granularity, not re-reads; gather_roof is the rate THIS device gave, in this run, for nothing but uniformly "
+                                 "random row fetches from this index (chn_index_gather_roof), and the kernel's probe rate as a fraction of it",
                          "other_kernels_avg_ms": {"k_count_wavelog": k2_ms / max(k2_n, 1), "k_model_call": k3_ms / max(k3_n, 1),
                                                   "whole_chain": chain_ms / max(chain_n, 1),
                                                   "note": "count and model+call run on a side stream under the next batch's minimise+probe"}},

@@ -66,7 +66,7 @@ EXPORTS = ["chn_index_create", "chn_index_upload_rows", "chn_index_device_words"
            "chn_model_set", "chn_batch_submit", "chn_batch_wait", "chn_stream_sync", "chn_classify_counts", "chn_stream_profile",
            "chn_stream_last_batch_bytes", "chn_synth_genomes", "chn_synth_fill_index", "chn_synth_plant", "chn_synth_reads",
            "chn_device_free", "chn_device_download", "chn_device_malloc", "chn_device_upload", "chn_host_alloc", "chn_host_free", "chn_shard_minimise",
-           "chn_shard_probe", "chn_shard_finish", "chn_shardx_minimise", "chn_shardx_counts", "chn_shardx_queries", "chn_shardx_serve", "chn_shardx_finish", "chn_minimisers", "chn_index_emplace", "chn_index_decode_ef", "chn_index_bin_popcounts", "chn_last_error", "chn_version"]
+           "chn_shard_probe", "chn_shard_finish", "chn_shardx_minimise", "chn_shardx_counts", "chn_shardx_queries", "chn_shardx_serve", "chn_shardx_finish", "chn_minimisers", "chn_index_emplace", "chn_index_decode_ef", "chn_index_bin_popcounts", "chn_index_gather_roof", "chn_last_error", "chn_version"]
 
 _L.chn_last_error.restype = C.c_char_p
 _L.chn_version.restype = C.c_char_p
@@ -88,6 +88,7 @@ _L.chn_stream_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.
 _L.chn_stream_last_batch_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 _L.chn_synth_genomes.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
 _L.chn_synth_fill_index.argtypes = [C.c_void_p, C.c_uint64, C.c_double]
+_L.chn_index_gather_roof.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
 _L.chn_synth_plant.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p]
 _L.chn_synth_reads.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                C.c_double, C.c_double, C.c_float, C.POINTER(SynthReadsOut)]
@@ -209,6 +210,12 @@ class Index:
     def emplace(self, values, bin_index):
         values = np.ascontiguousarray(values, dtype=np.uint64)
         _chk(_L.chn_index_emplace(self.h, values.ctypes.data, values.size, bin_index))
+
+    def gather_roof(self, nt=True):
+        """row fetches per second this device sustains for nothing but random probes of this index (measurement aid)"""
+        r = C.c_double()
+        _chk(_L.chn_index_gather_roof(self.h, 1 if nt else 0, C.byref(r)))
+        return r.value
 
     def synth_fill(self, seed, density):
         _chk(_L.chn_synth_fill_index(self.h, seed, density))

@@ -291,6 +291,10 @@ int chn_stream_profile(chn_stream *s, int which, double *total_ms, uint64_t *lau
 int chn_stream_last_batch_bytes(chn_stream *s, uint64_t *bytes, uint64_t *total_minimisers);
 
 /* ---- synthetic workload fabrication on the device (bench / tests; no reference counterpart) ---------- */
+/* Measurement aid: the rate this device sustains for NOTHING BUT the index's probe pattern -- independent uniformly random row
+ * fetches of 8 * bin_words bytes from THIS index's words (one load per thread in flight, 32 wavefronts per CU, `nt` cache policy if
+ * nt != 0) -- in row fetches per second.  bench.py reports k_minimise_probe's probe rate against it (roofline.gather_roof). */
+int chn_index_gather_roof(chn_index *idx, int nt, double *fetches_per_s);
 /* Random 2-bit genomes: n_genomes x genome_len bases (genome_len multiple of 64), counter-based PRNG. */
 int chn_synth_genomes(int device, uint64_t seed, uint64_t n_genomes, uint64_t genome_len, uint32_t **dev_bases2);
 /* Set every bit of user bins [0,B) of every row with probability `density` (background fill). */
