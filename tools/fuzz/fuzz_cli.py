@@ -34,8 +34,23 @@ def write_reads(path, names, seqs, r, fastq, gz, wrapw, crlf):
             out.append(">" + nm + eol + wrap(s) + eol)
     data = "".join(out).encode()
     if gz:
-        with gzip.open(path, "wb") as f:
-            f.write(data)
+        kind = r.random()
+        if kind < 0.35:  # BGZF: members of random size (the reader inflates them in parallel)
+            import struct, zlib
+            block = int(r.choice([200, 3000, 65280]))
+            with open(path, "wb") as f:
+                for c in [data[i:i + block] for i in range(0, len(data), block)] + [b""]:
+                    co = zlib.compressobj(int(r.choice([1, 6])), zlib.DEFLATED, -15)
+                    z = co.compress(c) + co.flush()
+                    f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(z) + 8 - 1) + z +
+                            struct.pack("<II", zlib.crc32(c) & 0xFFFFFFFF, len(c)))
+        else:  # one stream (or two members); the chunked inflate is forced onto small files by CHARON_INFLATE_CHUNK in trial()
+            with open(path, "wb") as f:
+                cut = len(data) // 2 if kind > 0.8 else len(data)
+                cut = data.rfind(b"\n", 0, cut) + 1 if cut < len(data) else cut
+                f.write(gzip.compress(data[:cut], int(r.choice([1, 6, 9]))))
+                if cut < len(data):
+                    f.write(gzip.compress(data[cut:], 6))
     else:
         with open(path, "wb") as f:
             f.write(data)
@@ -101,6 +116,8 @@ def trial(r, d):
     want = oidx.dehost_files(files_arg[0], files_arg[1] if paired else "", **kw)
     env = dict(os.environ)
     env["CHARON_BATCH_READS"] = str(int(r.choice([1, 7, 64, 1000, 65536])))
+    if r.random() < 0.7:
+        env["CHARON_INFLATE_CHUNK"] = str(int(r.choice([1024, 4096, 30000])))
     threads = int(r.choice([1, 3, 8]))
     p = subprocess.run([EXE, "dehost", "--db", os.path.join(d, "x.idx"), "-t", str(threads), "--log", os.path.join(d, "log")] + args + files_arg,
                        cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
