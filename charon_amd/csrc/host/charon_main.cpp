@@ -157,6 +157,34 @@ int main(int argc, char **argv) {
             return total == ztotal || std::getenv("CHARON_SKIP_ZLIB") ? 0 : 3;
         } catch (std::exception &e) { std::cerr << "charon: " << e.what() << std::endl; return 1; }
     }
+    if (sub == "_gfmt") {  // hidden self-test: format_g6 against printf's %g on random values of every kind a row holds
+        const unsigned long long n = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 1000000ULL;
+        unsigned long long x = argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 1, bad = 0, fast = 0;
+        auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+        char a[64], b[64];
+        for (unsigned long long i = 0; i < n; ++i) {
+            double v;
+            const unsigned kind = (unsigned)(rnd() % 8);
+            const double u = (double)(rnd() >> 11) / 9007199254740992.0;
+            if (kind == 0) v = (double)(float)((double)(rnd() % 5000) / (double)(1 + rnd() % 5000));        // proportions: float(count) / float(n)
+            else if (kind == 1) v = (double)((float)(rnd() % 100000) / (float)(1 + rnd() % 100000));
+            else if (kind == 2) v = u;                                                                       // probabilities
+            else if (kind == 3) v = std::pow(10.0, -12.0 * u) * (double)(rnd() % 10);
+            else if (kind == 4) v = (double)(float)(40.0 * u);                                               // mean quality
+            else if (kind == 5) v = (double)(rnd() % 2000000) / 2.0 * (rnd() & 1 ? 1.0 : 1e-3);              // exact ties and near-ties
+            else if (kind == 6) v = ((double)(rnd() % 1000000) + 0.5) * std::pow(10.0, -(double)(rnd() % 10));
+            else { uint64_t bits = rnd(); std::memcpy(&v, &bits, 8); }                                       // anything, NaN and infinities included
+            if (rnd() % 16 == 0) v = -v;
+            std::snprintf(a, sizeof a, "%g", v);
+            const size_t len = format_g6(v, b);
+            b[len] = 0;
+            if (std::strcmp(a, b) != 0) { if (++bad < 10) std::cout << "mismatch: " << a << " vs " << b << "\n"; }
+            const double av = v < 0 ? -v : v;
+            if (av >= 1e-4 && av < 999999.0) ++fast;
+        }
+        std::cout << "format_g6: " << n << " values, " << fast << " in the fast range, " << bad << " mismatches\n";
+        return bad ? 1 : 0;
+    }
     if (sub == "_records") {  // hidden diagnostic: dump what the block reader sees (no GPU involved)
         try {
             if (argc < 3) return 2;
