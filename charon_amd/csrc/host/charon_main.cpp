@@ -188,6 +188,7 @@ int main(int argc, char **argv) {
     if (sub == "_records") {  // hidden diagnostic: dump what the block reader sees (no GPU involved)
         try {
             if (argc < 3) return 2;
+            if (const char *t = std::getenv("CHARON_READER_THREADS")) g_reader_threads = std::max(1, std::atoi(t));
             BlockReader in(argv[2]);
             RawBlock blk;
             const size_t max_recs = argc > 3 ? (size_t)std::atol(argv[3]) : 1000, max_bytes = argc > 4 ? (size_t)std::atol(argv[4]) : (1u << 20);
@@ -198,6 +199,7 @@ int main(int argc, char **argv) {
                     for (uint32_t i = 0; i < r.qual_len; ++i) qs += r.qual[i] - 33;
                     std::cout << std::string(r.id, r.id_len) << "\t" << r.seq_len << "\t" << r.qual_len << "\t" << qs << "\t" << h << "\n";
                 }
+            if (std::getenv("CHARON_DIAG_SPLIT")) std::cerr << "split: " << g_split_pieces << " pieces, " << g_split_records << " records taken in parallel\n";
             return 0;
         } catch (std::exception &e) { std::cerr << "charon: " << e.what() << std::endl; return 1; }
     }

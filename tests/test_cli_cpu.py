@@ -292,14 +292,14 @@ def test_one_stream_gz_decoded_in_chunks_equals_zlib(tmp_path):
 
 
 def test_damaged_gz_fails_like_zlib_never_crashes(tmp_path):
-    """bit flips and cuts anywhere in a .gz: this build's decoder (sequential and chunked) must fail where zlib fails and give
+    """bit flips and cuts anywhere in a .gz (60 damaged files): this build's decoder (sequential and chunked) must fail where zlib fails and give
     zlib's records where zlib succeeds (a flip in the header's mtime, say) -- and never die on a signal"""
     import gzip, random
     rnd = random.Random(5)
     blob = _fastq_blob(400, 3, lens=(80, 150, 300))
     good = gzip.compress(blob, 6)
     f = tmp_path / "d.fastq.gz"
-    for trial in range(120):
+    for trial in range(60):
         b = bytearray(good)
         kind = trial % 3
         if kind == 0:
@@ -325,3 +325,44 @@ def test_row_number_formatting_equals_printf_g():
     for seed in ("1", "99"):
         p = subprocess.run([EXE, "_gfmt", "3000000", seed], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert p.returncode == 0 and b" 0 mismatches" in p.stdout, p.stdout
+
+
+def test_mapped_fastq_split_by_several_threads_equals_the_sequential_parse(tmp_path):
+    """a mapped FASTQ file is cut at guessed record starts and parsed by several threads; a piece counts only if the piece before it
+    came to stand exactly on its start, and anything but a plain four-line record is left to the sequential parser -- so the records,
+    and the errors, must be those of one thread, whatever the file looks like"""
+    import random
+    rnd = random.Random(17)
+
+    def make(n, crlf=False, blanks=0.0, wrapped=0.0, empty=0.0, at_quals=0.5):
+        eol = "\r\n" if crlf else "\n"
+        out = []
+        for i in range(n):
+            L = 0 if rnd.random() < empty else rnd.choice([30, 150, 151, 1000, 5000])
+            s = "".join(rnd.choice("ACGTN") for _ in range(L))
+            q = "".join(chr(rnd.randint(33, 73)) for _ in range(L))
+            if L and rnd.random() < at_quals:
+                q = "@" + q[1:]
+            if L > 200 and rnd.random() < wrapped:
+                s = eol.join(s[j:j + 70] for j in range(0, L, 70)); q = eol.join(q[j:j + 70] for j in range(0, L, 70))
+            out.append("@r%d desc @x +y%s%s%s+%s%s%s" % (i, eol, s, eol, eol, q, eol))
+            if rnd.random() < blanks:
+                out.append(eol)
+        return "".join(out).encode()
+
+    cases = {"plain": make(6000), "crlf": make(5000, crlf=True), "blanks": make(5000, blanks=0.01), "wrapped": make(5000, wrapped=0.01),
+             "empty": make(6000, empty=0.01), "mixed": make(6000, crlf=True, blanks=0.005, wrapped=0.005, empty=0.005)}
+    cases["no_final_newline"] = cases["plain"].rstrip(b"\n")
+    cases["cut"] = cases["plain"][:len(cases["plain"]) * 3 // 4 - 17]
+    dmg = bytearray(cases["plain"]); dmg[len(dmg) // 2] = ord("\n")
+    cases["broken_line"] = bytes(dmg)
+    for name, data in cases.items():
+        f = tmp_path / (name + ".fastq")
+        f.write_bytes(data)
+        for recs, mbytes in (("100000", str(32 << 20)), ("5000", str(3 << 20))):
+            one = subprocess.run([EXE, "_records", str(f), recs, mbytes], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, CHARON_READER_THREADS="1"))
+            for t in ("3",) if name in ("crlf", "blanks", "empty") else ("3", "8"):
+                many = subprocess.run([EXE, "_records", str(f), recs, mbytes], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, CHARON_READER_THREADS=t))
+                assert many.returncode == one.returncode, (name, recs, mbytes, t, many.stderr[-300:], one.stderr[-300:])
+                assert many.stdout == one.stdout, (name, recs, mbytes, t)
+                assert many.stderr == one.stderr, (name, t, many.stderr[-300:], one.stderr[-300:])
