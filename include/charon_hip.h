@@ -185,10 +185,12 @@ typedef struct chn_batch {
 #define CHN_GZIP_TALLIES 0u
 #define CHN_GZIP_SIZES 1u
 #define CHN_GZIP_BOTH 2u
-#define CHN_GZIP_MAX_LEN 16384u
+#define CHN_GZIP_MAX_LEN 61440u  /* one wavefront holds the whole read in LDS; short reads run many wavefronts per CU, a 60 kb read one */
 #define CHN_GZIP_TALLY_WORDS 320u /* per read: [0,286) literal/length code frequencies, [286,316) distance code frequencies,
                                    * [316] status: 0 = tallies valid, non-zero = not handled on the device (longer than asked for,
-                                   * more than one deflate block): size this read on the host */
+                                   * more than one deflate block): size this read on the host.
+                                   * Long reads run few wavefronts per CU (one beyond 31 k letters): a caller with many idle host threads may prefer to keep
+                                   * reads beyond ~16 k letters for itself (gzip_tallies = 16384) */
 
 /* Per-read results (what a post-processed + classified ReadEntry holds, include/read_entry.hpp:23-32):
  * num_hashes_, counts_[C], unique_counts_[C], probabilities_[C], call_, confidence_score_.

@@ -412,7 +412,7 @@ def test_cli_gzip_column_from_device_tallies(tmp_path, oracle_lib):
     oidx.store(str(tmp_path / "z.idx"))
     oidx.free()
     recs = []
-    lengths = [1, 2, 3, 4, 5, 7, 19, 41, 150, 300, 1000, 5000, 5000, 5000, 9000, 16383, 16384, 16385, 20000, 33000, 70000]
+    lengths = [1, 2, 3, 4, 5, 7, 19, 41, 150, 300, 1000, 5000, 5000, 5000, 9000, 16383, 16384, 16385, 20000, 33000, 61440, 61441, 70000]
     for i in range(420):
         L = int(lengths[i % len(lengths)]) if i % 3 else int(r.integers(1, 4000))
         s = acgt[r.integers(0, 4, L)].copy()
@@ -438,18 +438,18 @@ def test_cli_gzip_column_from_device_tallies(tmp_path, oracle_lib):
             f.write(">z%d\n%s\n" % (i, s.decode()))
     args = ["--db", str(tmp_path / "z.idx"), "--min_quality", "0", str(tmp_path / "z.fasta")]
     outs = {}
-    for mode, env in (("gpu", {}), ("host", {"CHARON_GZIP_ON_HOST": "1"}), ("zlib", {"CHARON_ZLIB_ONLY": "1"})):
+    for mode, env in (("gpu", {}), ("gpu16k", {"CHARON_GZIP_GPU_MAX": "16384"}), ("host", {"CHARON_GZIP_ON_HOST": "1"}), ("zlib", {"CHARON_ZLIB_ONLY": "1"})):
         rc, out, err = run_cli(args, str(tmp_path), dict(env, CHARON_BATCH_READS="100"))
         assert rc == 0, err
         outs[mode] = out
-    assert outs["gpu"] == outs["zlib"] == outs["host"]
-    # ... and the device really did the work: everything up to 16 384 letters that fits one deflate block (the last run was the zlib one,
-    # so look at the log of a fresh default run)
+    assert outs["gpu"] == outs["zlib"] == outs["host"] == outs["gpu16k"]
+    # ... and the device really did the work: everything up to 61 440 letters (-t 1: long reads go to the device too) that fits one deflate
+    # block (the last run was the zlib one, so look at the log of a fresh default run)
     rc, out, err = run_cli(args, str(tmp_path))
     import re
     mm = re.search(r"gzip column: (\d+) reads sized from device deflate tallies", open(tmp_path / "charon.log").read())
-    n_dev = sum(1 for s in recs[1:] if len(s) <= 16384)  # (the dropped first read is tallied too, but harmlessly)
-    assert mm and n_dev - 5 <= int(mm.group(1)) <= n_dev + 1
+    n_dev = sum(1 for s in recs[1:] if len(s) <= 61440)  # (the dropped first read is tallied too, but harmlessly)
+    assert mm and n_dev - 12 <= int(mm.group(1)) <= n_dev + 1  # (a few long low-match reads need a second deflate block: host)
     assert len(outs["gpu"].strip().split("\n")) == len(recs) - 1
     # classify gates on the column (min_compression 0.15): low-complexity reads lose their call in every mode alike
     # pairs: both mates in one gzip member

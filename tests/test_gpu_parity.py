@@ -817,8 +817,9 @@ def test_gzip_sizes_on_the_device_equal_zlib(api, oracle_lib):
     gs = [util.random_seq(r, 4000), util.random_seq(r, 4000)]
     oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [0, 1], ["host", "microbial"])
     g = util.gpu_index_from_oracle(api, oidx)
-    reads = [b"A", b"AC", b"ACG", b"ACGTN", b"A" * 1000, b"ACGT" * 500, b"N" * 300, b"AAC" * 700, gs[0][:700] * 3, util.random_seq(r, 17000)]
-    for n in (4, 7, 10, 16, 33, 70, 150, 400, 1000, 2500, 5000, 9000, 16384):
+    reads = [b"A", b"AC", b"ACG", b"ACGTN", b"A" * 1000, b"ACGT" * 500, b"N" * 300, b"AAC" * 700, gs[0][:700] * 3, util.random_seq(r, 17000), util.random_seq(r, 62000),
+             b"A" * 50000, b"ACGTTGCA" * 7000]
+    for n in (4, 7, 10, 16, 33, 70, 150, 400, 1000, 2500, 5000, 9000, 16384, 24000, 40000, 61440):
         reads.append(util.random_seq(r, n))
         reads.append(bytes(r.choice(list(b"ACGTN"), n, p=[0.3, 0.2, 0.2, 0.2, 0.1]).astype(np.uint8)))
     for k in range(60):  # low-entropy and skewed compositions: long codes, few symbols
@@ -832,21 +833,26 @@ def test_gzip_sizes_on_the_device_equal_zlib(api, oracle_lib):
     p = pack.pack_reads(reads)
     st = api.Stream(g, len(reads), p["n_bases"])
     st.set_model(api.default_model(2, 0))
-    st.submit_host(p, np.full(len(reads), 40.0, np.float32), None, gzip_tallies=16384, gzip_output=2)
+    st.submit_host(p, np.full(len(reads), 40.0, np.float32), None, gzip_tallies=61440, gzip_output=2)
     out = st.wait_host()
     sizes, status = out["gzip_sizes"], out["gzip_tallies"][:, 316]
 
     def zsize(b):
         co = zlib.compressobj(6, zlib.DEFLATED, 31, 8)
         return len(co.compress(b) + co.flush())
+    on_device = 0
     for i, rd in enumerate(reads):
-        if len(rd) > 16384:
+        if len(rd) > 61440:
             assert status[i] != 0 and sizes[i] == 0
             continue
-        assert status[i] == 0, i
+        if status[i] != 0:  # more than 16 382 symbols: a second deflate block -- only long reads with few matches may say so
+            assert len(rd) > 16383 * 3 // 2 and sizes[i] == 0, (i, len(rd))
+            continue
+        on_device += 1
         assert int(sizes[i]) == zsize(rd), (i, len(rd), rd[:40])
+    assert on_device >= len(reads) - 6
     # sizes only: no tallies come back, the same numbers do
-    st.submit_host(p, np.full(len(reads), 40.0, np.float32), None, gzip_tallies=16384, gzip_output=1)
+    st.submit_host(p, np.full(len(reads), 40.0, np.float32), None, gzip_tallies=61440, gzip_output=1)
     out1 = st.wait_host()
     assert "gzip_tallies" not in out1 and np.array_equal(out1["gzip_sizes"], sizes)
     st.destroy()
