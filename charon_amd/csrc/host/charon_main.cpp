@@ -14,7 +14,7 @@
 // --extract writes <prefix>_<category>[_1|_2]<ext>.gz like src/dehost_main.cpp:515-536 / include/result.hpp:118-128 (plain gzip
 // members; record layout as seqan3's sequence_file_output, which is recalled, not verified).
 // `charon classify` (src/classify_main.cpp) shares the loop: call_category for every read, gamma / beta models (--dist), its own defaults.
-// Not implemented: .bz2 input.
+// .bz2 input: this build's own block-parallel bzip2 decoder (bz2_stream.inc; libbz2 is not in the image).
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
@@ -72,6 +72,7 @@ bool g_gzip_emulator = true;
 #include "dehost_args.inc"
 #include "index_file.inc"
 #include "inflate_stream.inc"
+#include "bz2_stream.inc"
 #include "fastx_reader.inc"
 #include "result.inc"
 #include "dehost.inc"
@@ -107,6 +108,29 @@ int main(int argc, char **argv) {
                     const uint32_t e = d.sizer.size_padded(reinterpret_cast<const uint8_t *>(d.up.data()), n);
                     std::cout << std::string(r.id, r.id_len) << "\t" << d.zlib_size(n) << "\t" << e << "\n";
                 }
+            return 0;
+        } catch (std::exception &e) { std::cerr << "charon: " << e.what() << std::endl; return 1; }
+    }
+    if (sub == "_bunzip2") {  // hidden diagnostic: decode a .bz2 with this build's decoder to stdout; block statistics on stderr
+        try {
+            if (argc < 3) return 2;
+            if (const char *t = std::getenv("CHARON_READER_THREADS")) g_reader_threads = std::max(1, std::atoi(t));
+            const size_t piece = argc > 3 ? (size_t)std::atol(argv[3]) : ((size_t)64 << 20);
+            auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+            const double t0 = now();
+            Bz2Source bz;
+            bz.open(argv[2]);
+            Slab buf;
+            unsigned long long total = 0;
+            const bool quiet = std::getenv("CHARON_BUNZIP2_QUIET") != nullptr;
+            while (!bz.at_end()) {
+                buf.clear();
+                bz.fill(buf, piece);
+                total += buf.size();
+                if (!quiet && !buf.empty() && std::fwrite(buf.data(), 1, buf.size(), stdout) != buf.size()) return 1;
+            }
+            std::fflush(stdout);
+            std::cerr << "bunzip2: " << total << " bytes, " << bz.blocks_counted() << " blocks counted, " << bz.blocks_wasted() << " discarded, " << (now() - t0) << " s\n";
             return 0;
         } catch (std::exception &e) { std::cerr << "charon: " << e.what() << std::endl; return 1; }
     }

@@ -149,6 +149,12 @@ def test_cli_reader_formats(tmp_path, oracle_lib):
             rc, out, err = run_cli(["--db", str(tmp_path / "f.idx")] + extra + [str(tmp_path / name)], str(tmp_path), env)
             assert rc == 0, err
             assert_same_tsv(out, want)
+    # the same file as .bz2 (this build's own block-parallel decoder): same rows
+    import bz2
+    (tmp_path / "z.fastq.bz2").write_bytes(bz2.compress(open(tmp_path / "w.fastq", "rb").read(), 1))
+    rc, out, err = run_cli(["--db", str(tmp_path / "f.idx"), "-t", "4", str(tmp_path / "z.fastq.bz2")], str(tmp_path))
+    assert rc == 0, err
+    assert_same_tsv(out, oidx.dehost_files(str(tmp_path / "w.fastq"), min_quality=15.0))
     # an illegal sequence character is a parse error (non-zero exit), as in seqan3
     with open(tmp_path / "bad.fastq", "w") as f:
         f.write("@x\nACGTXACGT\n+\nIIIIIIIII\n")
