@@ -1,6 +1,6 @@
 """Time-boxed randomised soak of the drop-in boundary: `charon dehost` (GPU) vs the oracle's dehost on random indexes and read files.
     python tools/fuzz/fuzz_cli.py <seconds> <seed>     (needs a GPU)
-Varies: bins / categories / k / w, FASTQ vs FASTA, gz, wrapped lines, CRLF, lower case + IUPAC, zero-length reads, single vs paired,
+Varies: bins / categories / k / w, FASTQ vs FASTA, gz / BGZF / bz2, wrapped lines, CRLF, lower case + IUPAC, zero-length reads, single vs paired,
 batch size (CHARON_BATCH_READS), -t, --extract with a small --num_reads_to_fit (training path), thresholds."""
 import gzip
 import os
@@ -54,6 +54,7 @@ def write_reads(path, names, seqs, r, fastq, gz, wrapw, crlf):
     else:
         with open(path, "wb") as f:
             f.write(data)
+    return data
 
 
 def trial(r, d):
@@ -77,6 +78,7 @@ def trial(r, d):
     gz = bool(r.random() < 0.3)
     wrapw = int(r.choice([0, 0, 61]))
     crlf = bool(r.random() < 0.15)
+    bz = bool(not gz and r.random() < 0.15)  # .bz2 for the front end (its own decoder), the plain twin for the oracle's reader
     ext = (".fastq" if fastq else ".fasta") + (".gz" if gz else "")
 
     def spice(s):
@@ -108,12 +110,24 @@ def trial(r, d):
         cf = int(r.choice([0, 3, 30, 130, 200]))
         args += ["--confidence", str(cf)]
         kw["confidence"] = cf
-    extract = r.random() < 0.25
+    if bz:
+        import bz2
+        twins = []
+        for f in files_arg:
+            data = open(f, "rb").read()
+            cut = data.rfind(b"\n", 0, len(data) // 2) + 1
+            blob = bz2.compress(data, int(r.choice([1, 9]))) if r.random() < 0.6 else bz2.compress(data[:cut], 1) + bz2.compress(data[cut:], 5)
+            open(f + ".bz2", "wb").write(blob)
+            twins.append(f + ".bz2")
+        oracle_files, files_arg = files_arg, twins
+    else:
+        oracle_files = files_arg
+    extract = r.random() < 0.25 and not bz  # (get_extension gives ".bz2": the reference's writer refuses such a name, and so does this build)
     if extract:
         nfit = int(r.choice([5, 20, 50]))
         args += ["--extract", cats[0], "--num_reads_to_fit", str(nfit), "--prefix", os.path.join(d, "ex")]
         kw.update(run_extract=True, num_reads_to_fit=nfit)
-    want = oidx.dehost_files(files_arg[0], files_arg[1] if paired else "", **kw)
+    want = oidx.dehost_files(oracle_files[0], oracle_files[1] if paired else "", **kw)
     env = dict(os.environ)
     env["CHARON_BATCH_READS"] = str(int(r.choice([1, 7, 64, 1000, 65536])))
     if r.random() < 0.7:
@@ -124,8 +138,8 @@ def trial(r, d):
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     assert_same_tsv(p.stdout.decode() if p.stdout else "", want) if (want.strip() or p.stdout.strip()) else None
     oidx.free()
-    return "k=%d w=%d files=%d cats=%d n=%d lmax=%d paired=%d fastq=%d gz=%d wrap=%d crlf=%d extract=%d batch=%s t=%d rows=%d" % (
-        k, w, nfiles, len(cats), n, lmax, paired, fastq, gz, wrapw, crlf, extract, env["CHARON_BATCH_READS"], threads, len(want.strip().split("\n")) if want.strip() else 0)
+    return "k=%d w=%d files=%d cats=%d n=%d lmax=%d paired=%d fastq=%d gz=%d bz2=%d wrap=%d crlf=%d extract=%d batch=%s t=%d rows=%d" % (
+        k, w, nfiles, len(cats), n, lmax, paired, fastq, gz, bz, wrapw, crlf, extract, env["CHARON_BATCH_READS"], threads, len(want.strip().split("\n")) if want.strip() else 0)
 
 
 def main():
