@@ -216,11 +216,18 @@ def main():
         step_no[0] += 1
         st.shardx_minimise_device(n_reads, reads.n_bases, reads.bases2, reads.seg1_offset, reads.seg1_length, reads.mean_quality, reads.compression)
 
-    def sparse_rest(st, tag):
-        """queries -> (all-to-all) -> serve -> (all-to-all back) -> AND / count / call"""
+    def sparse_rest(st, tag, before_serve=None):
+        """queries -> (all-to-all) -> serve -> (all-to-all back) -> AND / count / call.  before_serve: called once this batch's query
+        kernels are queued and before its row fetches are -- the caller queues the NEXT batch's minimise kernel there, so that this
+        VALU-bound kernel runs beside the HBM-bound row fetches instead of beside the short count / scatter kernels (which it slowed
+        3.5 x while the row fetches then ran alone: profiles/r02/timeline_rows_sparse.txt)"""
         n_probes, counts = st.shardx_counts(splits)
         q = xtensor((tag, "q"), n_probes, torch.int32)
         st.shardx_queries(q.data_ptr(), q.numel())
+        if before_serve is not None:
+            if not os.environ.get("CHARON_BENCH_SPARSE_NOSYNC"):
+                st.sync()  # the query kernels have run: the minimise kernel queued next starts beside the row fetches, not beside them
+            before_serve()
         if use_dist and world > 1:
             st.sync()
             if args.backend == "nccl":
@@ -252,9 +259,10 @@ def main():
         res = None
         sparse_minimise(sts[0])
         for i in range(k):
-            if i + 1 < k:
-                sparse_minimise(sts[(i + 1) % 2])  # queued before this batch's row fetches: the two overlap on the device
-            sparse_rest(sts[i % 2], i % 2)
+            nxt = (lambda j=i: sparse_minimise(sts[(j + 1) % 2])) if i + 1 < k else None
+            if os.environ.get("CHARON_BENCH_SPARSE_EARLY") and nxt is not None:  # diagnostic: the former order
+                nxt(); nxt = None
+            sparse_rest(sts[i % 2], i % 2, nxt)
             res = sts[i % 2].wait_device()
         return res
 
