@@ -252,6 +252,10 @@ def test_bz2_input_blocks_decoded_side_by_side_equal_libbz2(tmp_path):
     cut = blob.rfind(b"\n@read", 0, 1200000) + 1
     cases = {"l9": (blob, bz2.compress(blob, 9)), "l1": (blob, bz2.compress(blob, 1)), "runs": (runs, bz2.compress(runs, 2)),
              "empty": (b"", bz2.compress(b"")), "one": (b"x", bz2.compress(b"x")),
+             # periodic text: the inverse-BWT permutation of such a block has several cycles (the decoder's sixteen walkers then give way to
+             # the defining walk); one letter only: blocks of a few dozen bytes that expand to 45 MB each
+             "period2": (b"AC" * 1200000, bz2.compress(b"AC" * 1200000, 9)), "period28": (b"@r\nACGTACGTAC\n+\nIIIIIIIIII\n" * 70000, bz2.compress(b"@r\nACGTACGTAC\n+\nIIIIIIIIII\n" * 70000, 9)),
+             "oneletter": (b"A" * (3 << 24), bz2.compress(b"A" * (3 << 24), 9)),
              "streams": (blob, bz2.compress(blob[:cut], 9) + bz2.compress(b"", 1) + bz2.compress(blob[cut:], 3))}
     for name, (want, comp) in cases.items():
         f = tmp_path / (name + ".bz2")

@@ -13,7 +13,7 @@ EXE = os.environ.get("CHARON_FUZZ_EXE", "/tmp/asan/charon")
 rnd = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 blob = t._fastq_blob(600, 9, lens=(80, 150, 300, 2000))
 runs = b"A" * 5000 + b"ACGT" * 3000 + bytes(range(256)) * 20 + b"\n" * 300
-variants = [bz2.compress(blob, 9), bz2.compress(blob, 1), bz2.compress(runs, 1), bz2.compress(blob[:70000], 1) + bz2.compress(b"", 9) + bz2.compress(blob[70000:], 2)]
+variants = [bz2.compress(b"ACGTTGA" * 40000, 1), bz2.compress(blob, 9), bz2.compress(blob, 1), bz2.compress(runs, 1), bz2.compress(blob[:70000], 1) + bz2.compress(b"", 9) + bz2.compress(blob[70000:], 2)]
 bad = 0
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 accepted = 0
