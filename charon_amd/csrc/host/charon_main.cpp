@@ -53,6 +53,7 @@
 #endif
 #ifdef _OPENMP
 #include <omp.h>
+#include <parallel/algorithm>  // __gnu_parallel::sort (libstdc++ parallel mode, OpenMP): the index builder's minimiser sets
 #endif
 
 #include "charon_hip.h"

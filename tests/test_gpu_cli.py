@@ -249,8 +249,9 @@ def test_cli_index_builds_the_same_index_as_the_oracle(tmp_path, oracle_lib):
     assert (got.k, got.w, got.bins, got.bin_size, got.hash_funs) == (want.k, want.w, want.bins, want.bin_size, want.hash_funs)
     assert list(got.bin_to_cat) == list(want.bin_to_cat)
     assert np.array_equal(got.words(), want.words())
-    # chromosome-sized records are processed in overlapping pieces; force tiny pieces to exercise that path
-    p2 = subprocess.run([EXE, "index", "-p", str(tmp_path / "pieces"), "--log", str(tmp_path / "i.log"), str(tab)], stdout=subprocess.PIPE,
+    # chromosome-sized records are processed in overlapping pieces; force tiny pieces to exercise that path -- and build on five
+    # threads (several-thread sort of the minimiser sets, Elias-Fano arrays written by all threads at once): the same file, byte for byte
+    p2 = subprocess.run([EXE, "index", "-t", "5", "-p", str(tmp_path / "pieces"), "--log", str(tmp_path / "i.log"), str(tab)], stdout=subprocess.PIPE,
                         stderr=subprocess.PIPE, env=dict(os.environ, CHARON_INDEX_PIECE="8192"))
     assert p2.returncode == 0, p2.stderr.decode()
     assert open(tmp_path / "pieces.idx", "rb").read() == open(tmp_path / "built.idx", "rb").read()

@@ -24,7 +24,8 @@ for f in ("big.idx",):
         os.remove(os.path.join(work, f))
 exe = os.path.join(ROOT, "charon_amd", "bin", "charon")
 t0 = time.time()
-p = subprocess.run([exe, "index", "-t", threads, "-p", os.path.join(work, "big"), "--log", os.path.join(work, "i.log"), os.path.join(work, "refs.tsv")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+p = subprocess.run([exe, "index", "-t", threads, "-p", os.path.join(work, "big"), "--log", os.path.join(work, "i.log"), os.path.join(work, "refs.tsv")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, CHARON_TIMING="1"))
 dt = time.time() - t0
 print("charon index -t %s: rc=%d, 2 x %d Mb in %.1f s (%.1f Mb/s), index file %.1f MB" % (threads, p.returncode, mb, dt, 2 * mb / dt, os.path.getsize(os.path.join(work, "big.idx")) / 1e6 if p.returncode == 0 else 0))
+print(p.stderr.decode()[-600:])
 print(open(os.path.join(work, "i.log")).read()[-600:])
