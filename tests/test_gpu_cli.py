@@ -252,7 +252,7 @@ def test_cli_index_builds_the_same_index_as_the_oracle(tmp_path, oracle_lib):
     # chromosome-sized records are processed in overlapping pieces; force tiny pieces to exercise that path -- and build on five
     # threads (several-thread sort of the minimiser sets, Elias-Fano arrays written by all threads at once): the same file, byte for byte
     p2 = subprocess.run([EXE, "index", "-t", "5", "-p", str(tmp_path / "pieces"), "--log", str(tmp_path / "i.log"), str(tab)], stdout=subprocess.PIPE,
-                        stderr=subprocess.PIPE, env=dict(os.environ, CHARON_INDEX_PIECE="8192"))
+                        stderr=subprocess.PIPE, env=dict(os.environ, CHARON_INDEX_PIECE="8192", CHARON_PSORT_MIN="16"))
     assert p2.returncode == 0, p2.stderr.decode()
     assert open(tmp_path / "pieces.idx", "rb").read() == open(tmp_path / "built.idx", "rb").read()
     # and it is usable: dehost some reads with it, same TSV as the oracle on the oracle-built twin
