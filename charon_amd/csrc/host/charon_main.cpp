@@ -40,6 +40,7 @@
 #include <stdexcept>
 #include <string>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
