@@ -313,9 +313,8 @@ def main():
     if elapsed / max(1, args.steps) < 2e-3 and not rows_mode and not sparse_mode:
         plain = api.Stream(index, n_reads, max_bases, profile=False)
         plain.set_model(api.default_model(ncat, 0, paired=paired))
-        depth = max(1, min(args.inflight, 3, args.steps))
-
         def plain_steps(k):
+            depth = max(1, min(args.inflight, 3, k))  # (per call: every batch submitted here is waited for here)
             for _ in range(depth - 1):
                 submit(plain)
             for i in range(k):

@@ -1,0 +1,53 @@
+"""bench.py's contract, on the toy workload: one JSON line with the fields the driver reads, a roofline object for the dominant kernel
+and a cpu_baseline object whose sample was checked against the GPU rows -- so that a change to the bench cannot silently drop a field."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench(*args):
+    p = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--workload", "small", "--steps", "3", "--warmup", "1"] + list(args),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout  # ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_line_has_the_contract_fields():
+    d = _bench()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "reads/s" and d["dtype"] == "u64" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["reads_per_step_per_gpu"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert "workload" in d["config"] and "input" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "algorithmic_bytes_per_launch"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
+    assert r["avg_launch_ms"] <= d["ms_per_step"] * 1.05  # the kernel cannot take longer than the step it is part of
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["gpu_parity_on_sample"] is True
+    # sub-millisecond steps are also timed without kernel events, and that figure cannot exceed the one with them by much
+    ne = d["config"]["ms_per_step_without_kernel_events"]
+    assert ne is None or 0 < ne <= d["ms_per_step"] * 1.25
+
+
+def test_bench_row_sharded_modes_run_at_one_rank():
+    for mode in ("rows", "rows-dense"):
+        d = _bench("--shard", mode, "--no-cpu-baseline")
+        assert d["value"] > 0 and d["n_gpus"] == 1
+        assert "sharded" in d["config"]["sharding"]
