@@ -12,8 +12,8 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-def _bench(*args):
-    p = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--workload", "small", "--steps", "3", "--warmup", "1"] + list(args),
+def _bench(*args, base=("--workload", "small", "--steps", "3", "--warmup", "1")):
+    p = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py")] + list(base) + list(args),
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -51,3 +51,12 @@ def test_bench_row_sharded_modes_run_at_one_rank():
         d = _bench("--shard", mode, "--no-cpu-baseline")
         assert d["value"] > 0 and d["n_gpus"] == 1
         assert "sharded" in d["config"]["sharding"]
+
+
+def test_bench_small_paired_batches_report_the_step_without_kernel_events():
+    """BASELINE configs[4] at the CLI's batch size: paired 2 x 150 b reads, 8 192 pairs per batch, call_category over 8 categories"""
+    d = _bench(base=("--workload", "cfg5", "--reads-per-step", "8192", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-pcie"))
+    assert d["config"]["reads_per_step_per_gpu"] == 8192 and d["unit"] in ("pairs/s", "reads/s")
+    ne = d["config"]["ms_per_step_without_kernel_events"]
+    assert ne is not None and 0 < ne <= d["ms_per_step"] * 1.25
+    assert d["roofline"]["avg_launch_ms"] <= ne * 1.05  # launches collapsed: the step is the probe kernel plus a few per cent
