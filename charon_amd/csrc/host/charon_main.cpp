@@ -22,6 +22,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <future>
 #include <deque>
 #include <mutex>
 #include <thread>
