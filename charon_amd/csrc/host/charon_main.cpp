@@ -212,6 +212,32 @@ int main(int argc, char **argv) {
         std::cout << "format_g6: " << n << " values, " << fast << " in the fast range, " << bad << " mismatches\n";
         return bad ? 1 : 0;
     }
+    if (sub == "_efcheck") {  // hidden diagnostic: Elias-Fano arrays written bit by bit in order (add) and by several threads at once (add_at)
+        try {
+            if (argc < 6) return 2;
+            const uint64_t seed = std::strtoull(argv[2], nullptr, 10), nwords = std::strtoull(argv[3], nullptr, 10);
+            const double density = std::atof(argv[4]);
+            const int threads = std::max(1, std::atoi(argv[5]));
+            std::vector<uint64_t> words(nwords);
+            uint64_t x = seed * 0x9E3779B97F4A7C15ULL + 1, ones = 0;
+            auto rnd = [&x]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+            for (uint64_t i = 0; i < nwords; ++i) {
+                uint64_t w = 0;
+                for (int b = 0; b < 64; ++b) if ((double)(rnd() >> 11) * (1.0 / 9007199254740992.0) < density) w |= 1ULL << b;
+                words[i] = w; ones += (uint64_t)__builtin_popcountll(w);
+            }
+            EliasFanoWriter a, b;
+            a.begin(nwords * 64, ones); b.begin(nwords * 64, ones);
+            for (uint64_t i = 0; i < nwords; ++i) { uint64_t w = words[i]; while (w) { a.add(i * 64 + (uint64_t)__builtin_ctzll(w)); w &= w - 1; } }
+            // the index builder's own routine, in two blocks so that `before` is exercised too
+            const uint64_t half = nwords / 2;
+            uint64_t got = ef_add_block(b, words.data(), half, 0, 0, threads);
+            got += ef_add_block(b, words.data() + half, nwords - half, half * 64, got, threads);
+            const bool same = a.low == b.low && a.high == b.high && a.k == ones && got == ones;
+            std::cout << "ones " << ones << " wl " << (int)a.wl << " low words " << a.low.size() << " high words " << a.high.size() << " same " << (same ? 1 : 0) << "\n";
+            return same ? 0 : 1;
+        } catch (std::exception &e) { std::cerr << "charon: " << e.what() << std::endl; return 1; }
+    }
     if (sub == "_records") {  // hidden diagnostic: dump what the block reader sees (no GPU involved)
         try {
             if (argc < 3) return 2;

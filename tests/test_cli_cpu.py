@@ -423,3 +423,12 @@ def test_mapped_fastq_split_by_several_threads_equals_the_sequential_parse(tmp_p
                 assert many.returncode == one.returncode, (name, recs, mbytes, t, many.stderr[-300:], one.stderr[-300:])
                 assert many.stdout == one.stdout, (name, recs, mbytes, t)
                 assert many.stderr == one.stderr, (name, t, many.stderr[-300:], one.stderr[-300:])
+
+
+def test_elias_fano_arrays_written_by_several_threads_equal_the_sequential_writer():
+    """`charon index` writes the sd_vector's low / high arrays from all its threads at once (a set bit's place depends only on its
+    position and on the number of set bits before it; the words at the seams between two threads' stretches are OR-ed atomically):
+    the arrays must be the ones the bit-by-bit writer produces, for any density and thread count (charon_amd/csrc/host/index_builder.inc)"""
+    for seed, nwords, density, threads in ((1, 5000, 0.2, 7), (2, 1, 0.5, 4), (3, 64, 1.0, 3), (4, 20000, 0.001, 8), (5, 3000, 0.02, 16), (6, 2, 0.0, 5), (7, 777, 0.6, 2)):
+        rc, out, err = run(["_efcheck", str(seed), str(nwords), str(density), str(threads)])
+        assert rc == 0 and " same 1" in out, (seed, nwords, density, threads, out, err)
