@@ -73,6 +73,7 @@ bool g_gzip_emulator = true;
 
 #include "log_util.inc"
 #include "dehost_args.inc"
+#include "sdsl_select.inc"
 #include "index_file.inc"
 #include "inflate_stream.inc"
 #include "bz2_stream.inc"
@@ -236,6 +237,37 @@ int main(int argc, char **argv) {
             const bool same = a.low == b.low && a.high == b.high && a.k == ones && got == ones;
             std::cout << "ones " << ones << " wl " << (int)a.wl << " low words " << a.low.size() << " high words " << a.high.size() << " same " << (same ? 1 : 0) << "\n";
             return same ? 0 : 1;
+        } catch (std::exception &e) { std::cerr << "charon: " << e.what() << std::endl; return 1; }
+    }
+    if (sub == "_selmcl") {  // hidden diagnostic: the two select_support_mcl blocks of a bit vector (u64 bit count + words), built or verified (no GPU involved)
+        try {
+            if (argc < 6) return 2;
+            const std::string mode = argv[2];
+            const int threads = std::max(1, std::atoi(argv[5]));
+            auto slurp = [](const char *path) {
+                std::ifstream f(path, std::ios::binary);
+                if (!f) throw std::runtime_error(std::string("cannot open ") + path);
+                return std::string((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+            };
+            const std::string bv = slurp(argv[3]);
+            if (bv.size() < 8) return 2;
+            uint64_t nbits = 0;
+            std::memcpy(&nbits, bv.data(), 8);
+            std::vector<uint64_t> words((nbits + 63) / 64 + 1, 0);
+            if (bv.size() - 8 < (nbits + 63) / 64 * 8) return 2;
+            std::memcpy(words.data(), bv.data() + 8, (nbits + 63) / 64 * 8);
+            if (mode == "build") {
+                std::ofstream o(argv[4], std::ios::binary);
+                for (int bit = 1; bit >= 0; --bit) { const std::string b = selmcl::build(words.data(), nbits, bit == 1, threads); o.write(b.data(), (std::streamsize)b.size()); }
+                return o ? 0 : 1;
+            }
+            const std::string blocks = slurp(argv[4]);
+            selmcl::TailParser tp{blocks.data(), (uint64_t)blocks.size(), 0, 0};
+            selmcl::verify(tp, words.data(), nbits, true, threads);
+            selmcl::verify(tp, words.data(), nbits, false, threads);
+            if (tp.off != tp.len) tp.fail(std::to_string(tp.len - tp.off) + " bytes follow m_high_0_select");
+            std::cout << "select blocks agree with the bit vector\n";
+            return 0;
         } catch (std::exception &e) { std::cerr << "charon: " << e.what() << std::endl; return 1; }
     }
     if (sub == "_records") {  // hidden diagnostic: dump what the block reader sees (no GPU involved)

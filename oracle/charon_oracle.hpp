@@ -168,6 +168,165 @@ inline uint64_t hash_and_fit_row(uint64_t x, uint64_t seed, uint64_t bin_size, u
     return (uint64_t)(((u128)x * (u128)bin_size) >> 64);  // fastrange
 }
 
+// ---------------------------------------------------------------------------------------------
+// sdsl::int_vector<0> and sdsl::select_support_mcl<t_b, 1> (sdsl-lite v3, bundled with seqan3 @30bdf8d0; the
+// source is NOT in the image: [3P-recall], parity unpinned).  An sd_vector ends with two of them over m_high
+// (m_high_1_select, m_high_0_select) and upstream charon's archive(ibf_) (include/index.hpp:130) stores both,
+// so a file upstream can load needs them.  The construction below restates select_support_mcl.hpp's
+// initData / init_slow / init_fast STATEMENT BY STATEMENT (the product writer derives its rules from the
+// outcome instead: charon_amd/csrc/host/sdsl_select.inc; the two must agree byte for byte).
+// ---------------------------------------------------------------------------------------------
+struct IntVec {  // int_vector<0>: `n` entries of `width` bits, packed LSB first into 64-bit words
+    uint8_t width = 64;  // a default-constructed int_vector<0> has width 64 and no entries
+    uint64_t n = 0;
+    std::vector<uint64_t> words;
+    IntVec() {}
+    IntVec(uint64_t size, uint64_t def, uint8_t w) : width(w), n(size), words((size * w + 63) / 64 + 1, 0) { (void)def; }
+    bool empty() const { return n == 0; }
+    uint64_t bit_size() const { return n * width; }
+    uint64_t get(uint64_t i) const {
+        const uint64_t bit = i * width, wd = bit >> 6, sh = bit & 63;
+        uint64_t v = words[wd] >> sh;
+        if (sh + width > 64) v |= words[wd + 1] << (64 - sh);
+        return width == 64 ? v : (v & ((1ULL << width) - 1));
+    }
+    void set(uint64_t i, uint64_t v) {  // (entries are written once, onto zeros; the value is cut to `width` bits as sdsl does)
+        if (width < 64) v &= (1ULL << width) - 1;
+        const uint64_t bit = i * width, wd = bit >> 6, sh = bit & 63;
+        words[wd] |= v << sh;
+        if (sh + width > 64) words[wd + 1] |= v >> (64 - sh);
+    }
+};
+
+struct SelectMcl {
+    // the bit vector it supports
+    const uint64_t *v_words = nullptr;
+    uint64_t v_size = 0;
+    int t_b = 1;
+    // members, in the order cereal stores them
+    uint64_t m_arg_cnt = 0;
+    uint32_t m_logn = 0, m_logn2 = 0, m_logn4 = 0;
+    IntVec m_superblock;
+    std::vector<IntVec> m_longsuperblock;  // empty() <=> nullptr in sdsl
+    std::vector<IntVec> m_miniblock;
+
+    static unsigned hi(uint64_t x) { return x ? 63u - clz64(x) : 0u; }               // bits::hi
+    static unsigned sel(uint64_t x, unsigned i) { while (--i) x &= x - 1; return (unsigned)__builtin_ctzll(x); }  // bits::sel, i from 1
+    bool v_at(uint64_t i) const { return (v_words[i >> 6] >> (i & 63)) & 1; }
+    uint64_t v_word(uint64_t i) const { return v_words[i]; }  // padding bits behind v_size are 0, as in an sdsl bit_vector
+    // select_support_trait<t_b, 1>
+    bool found_arg(uint64_t i) const { return t_b ? v_at(i) : !v_at(i); }
+    uint64_t args_in_the_word(uint64_t w) const { return (uint64_t)__builtin_popcountll(t_b ? w : ~w); }
+    unsigned ith_arg_pos_in_the_word(uint64_t w, uint64_t i) const { return sel(t_b ? w : ~w, (unsigned)i); }
+    uint64_t arg_cnt() const {
+        uint64_t ones = 0;
+        for (uint64_t i = 0; i < v_size; ++i) ones += v_at(i);
+        return t_b ? ones : v_size - ones;
+    }
+
+    void initData() {
+        m_arg_cnt = 0;
+        m_logn = hi(((v_size + 63) >> 6) << 6) + 1;
+        m_logn2 = m_logn * m_logn;
+        m_logn4 = m_logn2 * m_logn2;
+        m_longsuperblock.clear();
+        m_miniblock.clear();
+    }
+    // select_support_mcl(const bit_vector *): init_slow for vectors below 100 000 bits, init_fast otherwise
+    void init(const uint64_t *words, uint64_t size, int b) {
+        v_words = words; v_size = size; t_b = b;
+        if (v_size < 100000) init_slow(); else init_fast();
+    }
+    void init_slow() {
+        initData();
+        m_arg_cnt = arg_cnt();
+        const uint64_t SUPER_BLOCK_SIZE = 4096;
+        if (m_arg_cnt == 0) return;
+        const uint64_t sb = (m_arg_cnt + SUPER_BLOCK_SIZE - 1) / SUPER_BLOCK_SIZE;
+        m_miniblock.assign(sb, IntVec());
+        m_superblock = IntVec(sb, 0, (uint8_t)m_logn);
+        std::vector<uint64_t> arg_position(SUPER_BLOCK_SIZE);
+        uint64_t cnt = 0, sb_cnt = 0;
+        for (uint64_t i = 0; i < v_size; ++i) {
+            if (!found_arg(i)) continue;
+            arg_position[cnt % SUPER_BLOCK_SIZE] = i;
+            ++cnt;
+            if (cnt % SUPER_BLOCK_SIZE == 0 || cnt == m_arg_cnt) {
+                m_superblock.set(sb_cnt, arg_position[0]);
+                const uint64_t pos_diff = arg_position[(cnt - 1) % SUPER_BLOCK_SIZE] - arg_position[0];
+                if (pos_diff > m_logn4) {  // longblock
+                    if (m_longsuperblock.empty()) m_longsuperblock.assign(sb, IntVec());
+                    m_longsuperblock[sb_cnt] = IntVec(SUPER_BLOCK_SIZE, 0, (uint8_t)(hi(arg_position[(cnt - 1) % SUPER_BLOCK_SIZE]) + 1));
+                    for (uint64_t j = 0; j <= (cnt - 1) % SUPER_BLOCK_SIZE; ++j) m_longsuperblock[sb_cnt].set(j, arg_position[j]);
+                } else {  // short block
+                    m_miniblock[sb_cnt] = IntVec(64, 0, (uint8_t)(hi(pos_diff) + 1));
+                    for (uint64_t j = 0; j <= (cnt - 1) % SUPER_BLOCK_SIZE; j += 64) m_miniblock[sb_cnt].set(j / 64, arg_position[j] - arg_position[0]);
+                }
+                ++sb_cnt;
+            }
+        }
+    }
+    void init_fast() {
+        initData();
+        m_arg_cnt = arg_cnt();
+        const uint64_t SUPER_BLOCK_SIZE = 64 * 64;
+        if (m_arg_cnt == 0) return;
+        const uint64_t sb = (m_arg_cnt + SUPER_BLOCK_SIZE - 1) / SUPER_BLOCK_SIZE;
+        m_miniblock.assign(sb, IntVec());
+        m_superblock = IntVec(sb, 0, (uint8_t)m_logn);
+        std::vector<uint64_t> arg_position(SUPER_BLOCK_SIZE);
+        uint64_t last_k64 = 1, sb_cnt = 0;
+        uint64_t cnt_old = 0, cnt_new = 0, last_k64_sum = 1;
+        for (uint64_t i = 0, wi = 0; i < (((v_size + 63) >> 6) << 6); i += 64, ++wi) {
+            const uint64_t data = v_word(wi);
+            cnt_new += args_in_the_word(data);
+            cnt_new = std::min(cnt_new, m_arg_cnt);  // zeros in the padding behind the vector are no args
+            if (cnt_new >= last_k64_sum) {
+                arg_position[last_k64 - 1] = i + ith_arg_pos_in_the_word(data, last_k64_sum - cnt_old);
+                last_k64 += 64;
+                last_k64_sum += 64;
+                if (last_k64 == SUPER_BLOCK_SIZE + 1) {
+                    m_superblock.set(sb_cnt, arg_position[0]);
+                    uint64_t pos_of_last_arg_in_the_block = arg_position[last_k64 - 65];
+                    for (uint64_t ii = arg_position[last_k64 - 65] + 1, j = last_k64 - 65; ii < v_size && j < SUPER_BLOCK_SIZE; ++ii)
+                        if (found_arg(ii)) { pos_of_last_arg_in_the_block = ii; ++j; }
+                    const uint64_t pos_diff = pos_of_last_arg_in_the_block - arg_position[0];
+                    if (pos_diff > m_logn4) {  // long block
+                        if (m_longsuperblock.empty()) m_longsuperblock.assign(sb + 1, IntVec());
+                        m_longsuperblock[sb_cnt] = IntVec(SUPER_BLOCK_SIZE, 0, (uint8_t)(hi(pos_of_last_arg_in_the_block) + 1));
+                        for (uint64_t j = arg_position[0], k = 0; k < SUPER_BLOCK_SIZE && j <= pos_of_last_arg_in_the_block; ++j)
+                            if (found_arg(j)) m_longsuperblock[sb_cnt].set(k++, j);
+                    } else {
+                        m_miniblock[sb_cnt] = IntVec(64, 0, (uint8_t)(hi(pos_diff) + 1));
+                        for (uint64_t j = 0; j < SUPER_BLOCK_SIZE; j += 64) m_miniblock[sb_cnt].set(j / 64, arg_position[j] - arg_position[0]);
+                    }
+                    ++sb_cnt;
+                    last_k64 = 1;
+                }
+            }
+            cnt_old = cnt_new;
+        }
+        if (last_k64 > 1) {  // handle last block: append long superblock
+            if (m_longsuperblock.empty()) m_longsuperblock.assign(sb + 1, IntVec());
+            m_longsuperblock[sb_cnt] = IntVec(SUPER_BLOCK_SIZE, 0, (uint8_t)(hi(v_size - 1) + 1));
+            for (uint64_t i = arg_position[0], k = 0; i < v_size; ++i)
+                if (found_arg(i)) m_longsuperblock[sb_cnt].set(k++, i);
+            ++sb_cnt;
+        }
+    }
+    // select_support_mcl::select(i), i from 1 -- reads only the stored blocks and, between two sampled args, the bit vector
+    uint64_t select(uint64_t i) const {
+        i = i - 1;
+        const uint64_t sb_idx = i >> 12, offset = i & 0xFFF;
+        if (!m_longsuperblock.empty() && !m_longsuperblock[sb_idx].empty()) return m_longsuperblock[sb_idx].get(offset);
+        if ((offset & 0x3F) == 0) return m_superblock.get(sb_idx) + m_miniblock[sb_idx].get(offset >> 6);
+        i = i - (sb_idx << 12) - ((offset >> 6) << 6);
+        uint64_t pos = m_superblock.get(sb_idx) + m_miniblock[sb_idx].get(offset >> 6) + 1;
+        for (;; ++pos)
+            if (found_arg(pos) && --i == 0) return pos;
+    }
+};
+
 // Elias-Fano bit vector = sdsl::sd_vector<> (storage of the *compressed* IBF the reference keeps in
 // RAM, include/index.hpp:26).  get_int() is what every reference probe costs.
 struct SdVector {
@@ -180,6 +339,9 @@ struct SdVector {
     // select_0 samples over `high`: position of every 2^SAMPLE_LOG-th zero
     static const unsigned SAMPLE_LOG = 9;
     std::vector<uint64_t> sel0_samples;
+    // the file's own select structures (load_index fills them when the file carries them; the probes above do not use them)
+    SelectMcl sel1, sel0;
+    bool has_sel = false;
 
     static unsigned hi(uint64_t x) { return x ? 63u - clz64(x) : 0u; }
 
@@ -433,6 +595,26 @@ struct BinWriter {
         pod<uint64_t>(bit_size);
         os.write(reinterpret_cast<const char *>(words.data()), (std::streamsize)(n_words * 8));
     }
+    void int_vector(const IntVec &v) { int_vector(v.width, v.bit_size(), v.words); }
+    // select_support_mcl's cereal save: arg_cnt, logn, logn2, logn4; then, if there are args, m_superblock, mini_or_long
+    // (bit i = superblock i has a miniblock; EMPTY when no long superblock exists) and per superblock its long or mini vector
+    void select_mcl(const SelectMcl &s) {
+        pod<uint64_t>(s.m_arg_cnt);
+        pod<uint32_t>(s.m_logn); pod<uint32_t>(s.m_logn2); pod<uint32_t>(s.m_logn4);
+        const uint64_t sb = (s.m_arg_cnt + 4095) >> 12;
+        if (!s.m_arg_cnt) return;
+        int_vector(s.m_superblock);
+        IntVec mini_or_long(0, 0, 1);
+        if (!s.m_longsuperblock.empty()) {
+            mini_or_long = IntVec(sb, 0, 1);
+            for (uint64_t i = 0; i < sb; ++i) mini_or_long.set(i, !s.m_miniblock[i].empty());
+        }
+        int_vector(mini_or_long);
+        for (uint64_t i = 0; i < sb; ++i) {
+            if (!mini_or_long.empty() && !mini_or_long.get(i)) int_vector(s.m_longsuperblock[i]);
+            else int_vector(s.m_miniblock[i]);
+        }
+    }
 };
 struct BinReader {
     std::istream &is;
@@ -460,6 +642,32 @@ struct BinReader {
         words.assign(n_words + 1, 0);
         is.read(reinterpret_cast<char *>(words.data()), (std::streamsize)(n_words * 8));
         if (!is) throw std::runtime_error("index file truncated inside int_vector");
+    }
+    IntVec int_vec() {
+        IntVec v; uint64_t bits;
+        int_vector(v.width, bits, v.words);
+        if (bits % v.width) throw std::runtime_error("int_vector bit size is not a multiple of its width");
+        v.n = bits / v.width;
+        return v;
+    }
+    bool at_end() { return is.peek() == std::char_traits<char>::eof(); }
+    // select_support_mcl's cereal load
+    void select_mcl(SelectMcl &s) {
+        s.m_arg_cnt = pod<uint64_t>();
+        s.m_logn = pod<uint32_t>(); s.m_logn2 = pod<uint32_t>(); s.m_logn4 = pod<uint32_t>();
+        const uint64_t sb = (s.m_arg_cnt + 4095) >> 12;
+        s.m_longsuperblock.clear(); s.m_miniblock.clear();
+        if (!s.m_arg_cnt) return;
+        s.m_superblock = int_vec();
+        if (s.m_superblock.n != sb) throw std::runtime_error("select_support_mcl: m_superblock size");
+        const IntVec mini_or_long = int_vec();
+        if (mini_or_long.width != 1 || (mini_or_long.n != 0 && mini_or_long.n != sb)) throw std::runtime_error("select_support_mcl: mini_or_long size");
+        if (!mini_or_long.empty()) s.m_longsuperblock.assign(sb, IntVec());
+        s.m_miniblock.assign(sb, IntVec());
+        for (uint64_t i = 0; i < sb; ++i) {
+            if (!mini_or_long.empty() && !mini_or_long.get(i)) s.m_longsuperblock[i] = int_vec();
+            else s.m_miniblock[i] = int_vec();
+        }
     }
 };
 
@@ -493,8 +701,12 @@ inline void store_index(const std::string &path, const Index &idx) {
     w.pod<uint8_t>(idx.ef.wl);
     w.int_vector(idx.ef.wl, idx.ef.ones * idx.ef.wl, idx.ef.low);
     w.int_vector(1, idx.ef.high_bits, idx.ef.high);
-    // The two trailing select_support_mcl structures are NOT written (readers of this project stop
-    // before them; a file for the real reference binary needs them -- SURVEY 8(f) item 2).
+    // m_high_1_select, m_high_0_select: the sd_vector's two select_support_mcl structures over m_high
+    for (int b = 1; b >= 0; --b) {
+        SelectMcl sel;
+        sel.init(idx.ef.high.data(), idx.ef.high_bits, b);
+        w.select_mcl(sel);
+    }
 }
 
 // src/load_index.cpp:8-15
@@ -539,6 +751,17 @@ inline void load_index(Index &idx, const std::string &path) {
     r.int_vector(width, bits, idx.ef.high);
     if (width != 1) throw std::runtime_error("m_high is not a bit vector");
     idx.ef.high_bits = bits;
+    // m_high_1_select / m_high_0_select, when the file carries them (files of an earlier build of this project end behind m_high)
+    idx.ef.has_sel = false;
+    if (!r.at_end()) {
+        r.select_mcl(idx.ef.sel1);
+        r.select_mcl(idx.ef.sel0);
+        if (!r.at_end()) throw std::runtime_error("bytes follow m_high_0_select");
+        idx.ef.sel1.v_words = idx.ef.sel0.v_words = idx.ef.high.data();
+        idx.ef.sel1.v_size = idx.ef.sel0.v_size = idx.ef.high_bits;
+        idx.ef.sel1.t_b = 1; idx.ef.sel0.t_b = 0;
+        idx.ef.has_sel = true;
+    }
     idx.ef.build_select();
     idx.has_ef = true;
     idx.decompress();

@@ -113,6 +113,19 @@ int orc_index_category_name(void *h, int c, char *buf, int cap) {
 }
 void orc_index_bulk_contains(void *h, uint64_t value, uint64_t *out) { ((Index *)h)->bulk_contains(value, out); }
 uint64_t orc_sd_get_int(void *h, uint64_t bit) { return ((Index *)h)->ef.get_int(bit); }
+// select_support_mcl blocks of a loaded file: 1 if present; orc_sd_select answers select_b(i), i from 1, from the stored blocks
+int orc_sd_has_select(void *h) { return ((Index *)h)->ef.has_sel ? 1 : 0; }
+uint64_t orc_sd_select_args(void *h, int b) { const SdVector &e = ((Index *)h)->ef; return b ? e.sel1.m_arg_cnt : e.sel0.m_arg_cnt; }
+uint64_t orc_sd_select(void *h, int b, uint64_t i) { const SdVector &e = ((Index *)h)->ef; return b ? e.sel1.select(i) : e.sel0.select(i); }
+// the two serialised select_support_mcl blocks (ones, then zeros) of a raw bit vector, as store_index appends them
+int orc_select_blocks(const uint64_t *words, uint64_t nbits, const char *path) {
+    try {
+        std::ofstream os(path, std::ios::binary);
+        BinWriter w(os);
+        for (int b = 1; b >= 0; --b) { SelectMcl s; s.init(words, nbits, b); w.select_mcl(s); }
+        return os ? 0 : -1;
+    } catch (std::exception &e) { std::fprintf(stderr, "%s\n", e.what()); return -1; }
+}
 
 // ---- the per-read path (A4-A10) on in-memory reads -------------------------------------------
 // seqs: concatenated ASCII bases; offsets[n+1]; mate_split[i] (or NULL) = length of mate 1 of read i

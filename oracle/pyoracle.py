@@ -85,6 +85,14 @@ def lib():
         L.orc_index_bulk_contains.argtypes = [C.c_void_p, C.c_uint64, u64p]
         L.orc_sd_get_int.restype = C.c_uint64
         L.orc_sd_get_int.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_sd_has_select.restype = C.c_int
+        L.orc_sd_has_select.argtypes = [C.c_void_p]
+        L.orc_sd_select_args.restype = C.c_uint64
+        L.orc_sd_select_args.argtypes = [C.c_void_p, C.c_int]
+        L.orc_sd_select.restype = C.c_uint64
+        L.orc_sd_select.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+        L.orc_select_blocks.restype = C.c_int
+        L.orc_select_blocks.argtypes = [u64p, C.c_uint64, C.c_char_p]
         L.orc_process_reads.restype = C.c_double
         L.orc_process_reads.argtypes = [C.c_void_p, C.c_char_p, u64p, C.c_uint64, C.c_void_p, C.c_char_p, C.c_float,
                                         C.POINTER(Thresholds), C.c_int] + [C.c_void_p] * 10
@@ -109,6 +117,13 @@ def lib():
 
 def _u64p(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def select_blocks(words, nbits, path):
+    """the two serialised select_support_mcl blocks (ones, zeros) of a raw bit vector, as store_index appends them"""
+    w = np.ascontiguousarray(words, np.uint64)
+    assert lib().orc_select_blocks(_u64p(w), nbits, path.encode()) == 0
+    return open(path, "rb").read()
 
 
 def kmer_hashes(seq, k, sigma=5):

@@ -246,6 +246,101 @@ def _int_vector(width, bits, value):
     return struct.pack("<BfQQ", width, 1.5, nwords, bits) + value.to_bytes(nwords * 8, "little")
 
 
+# ---- sdsl select_support_mcl over m_high (the two blocks that close an sd_vector in the file) -----
+# Third, independent statement of the layout ([3P-recall] of sdsl-lite v3's select_support_mcl.hpp): a writer that works from
+# the list of arg positions, a parser of the stored bytes, and select() as sdsl reads the stored blocks.
+def _hi(x):
+    return x.bit_length() - 1 if x else 0
+
+
+def _pack(width, n, vals):
+    v = 0
+    for i, x in enumerate(vals):
+        v |= (x & ((1 << width) - 1)) << (i * width)
+    return _int_vector(width, n * width, v)
+
+
+def bit_array(bits, nbits):
+    """python int (bit i = position i) -> numpy array of nbits 0/1 bytes"""
+    if isinstance(bits, np.ndarray):
+        return bits
+    raw = np.frombuffer(int(bits).to_bytes((nbits + 7) // 8 + 1, "little"), np.uint8)
+    return np.unpackbits(raw, bitorder="little")[:nbits]
+
+
+def select_blocks_write(bits, nbits, b):
+    """serialised select_support_mcl<b> of the bit vector `bits` (python int, bit i = position i, or a 0/1 array) of nbits bits"""
+    pos = [int(x) for x in np.flatnonzero(bit_array(bits, nbits) == b)]
+    logn = _hi(((nbits + 63) >> 6) << 6) + 1
+    out = struct.pack("<QIII", len(pos), logn, logn * logn, (logn * logn) ** 2)
+    if not pos:
+        return out
+    fast = nbits >= 100000
+    sb = (len(pos) + 4095) // 4096
+    first, kinds, blocks = [], [], []
+    for s_ in range(sb):
+        blk = pos[s_ * 4096:(s_ + 1) * 4096]
+        tail = fast and len(blk) <= 4032
+        # init_fast measures a superblock up to the first arg of the NEXT one (its scan for the last arg counts one arg too many)
+        last = pos[(s_ + 1) * 4096] if fast and (s_ + 1) * 4096 < len(pos) else blk[-1]
+        if tail or last - blk[0] > (logn * logn) ** 2:
+            kinds.append(0)
+            first.append(0 if tail else blk[0])
+            blocks.append(_pack(_hi(nbits - 1 if tail else last) + 1, 4096, blk))
+        else:
+            kinds.append(1)
+            first.append(blk[0])
+            blocks.append(_pack(_hi(last - blk[0]) + 1, 64, [p - blk[0] for p in blk[::64]]))
+    out += _pack(logn, sb, first)
+    out += _pack(1, sb, kinds) if 0 in kinds else _int_vector(1, 0, 0)
+    return out + b"".join(blocks)
+
+
+def select_blocks_parse(buf, off=0):
+    """-> (dict(arg_cnt, logn, superblock, mini_or_long, blocks), offset behind the block); vectors as (width, n, int)"""
+    def vec():
+        nonlocal off
+        width, gf, nwords, bits = struct.unpack_from("<BfQQ", buf, off)
+        off += 21
+        assert gf == 1.5 and 1 <= width <= 64 and nwords * 64 >= bits and bits % width == 0
+        v = int.from_bytes(buf[off:off + nwords * 8], "little")
+        off += nwords * 8
+        return (width, bits // width, v)
+
+    arg_cnt, logn, logn2, logn4 = struct.unpack_from("<QIII", buf, off)
+    off += 20
+    d = dict(arg_cnt=arg_cnt, logn=logn, logn2=logn2, logn4=logn4, superblock=None, mini_or_long=None, blocks=[])
+    if arg_cnt:
+        sb = (arg_cnt + 4095) >> 12
+        d["superblock"] = vec()
+        d["mini_or_long"] = vec()
+        assert d["superblock"][1] == sb and d["mini_or_long"][0] == 1 and d["mini_or_long"][1] in (0, sb)
+        d["blocks"] = [vec() for _ in range(sb)]
+    return d, off
+
+
+def _vget(v, i):
+    width, n, val = v
+    assert i < n
+    return (val >> (i * width)) & ((1 << width) - 1)
+
+
+def select_from_blocks(d, bits, b, i):
+    """select_b(i), i from 1, read from the STORED blocks the way select_support_mcl::select does (bits: 0/1 array, see bit_array)"""
+    i -= 1
+    sb_idx, offset = i >> 12, i & 0xFFF
+    mol = d["mini_or_long"]
+    if mol[1] and not _vget(mol, sb_idx):  # long superblock: the position verbatim
+        return _vget(d["blocks"][sb_idx], offset)
+    pos = _vget(d["superblock"], sb_idx) + _vget(d["blocks"][sb_idx], offset >> 6)
+    need = offset & 0x3F
+    while need:  # scan the bit vector behind the sampled arg
+        pos += 1
+        if bits[pos] == b:
+            need -= 1
+    return pos
+
+
 def write_index(path, k, w, max_fpr, categories, filepath_to_bin, bin_to_category, num_files, records_per_bin,
                 hashes_per_bin, ibf):
     s = lambda x: struct.pack("<Q", len(x)) + x.encode()
@@ -266,6 +361,7 @@ def write_index(path, k, w, max_fpr, categories, filepath_to_bin, bin_to_categor
             val &= val - 1
     wl, lowbits, low, highbits, high = ef_encode(positions, ibf.tb * ibf.bin_size)
     out += struct.pack("<QB", ibf.tb * ibf.bin_size, wl) + _int_vector(wl, lowbits, low) + _int_vector(1, highbits, high)
+    out += select_blocks_write(high, highbits, 1) + select_blocks_write(high, highbits, 0)  # m_high_1_select, m_high_0_select
     open(path, "wb").write(out)
 
 
@@ -306,6 +402,11 @@ def read_index(path):
     msize, wl = take("QB")
     lw, lbits, low = int_vector()
     hw, hbits, high = int_vector()
+    select1 = select0 = None
+    if off[0] < len(buf):  # the sd_vector's two select structures (absent in files of an earlier build of this project)
+        select1, off[0] = select_blocks_parse(buf, off[0])
+        select0, off[0] = select_blocks_parse(buf, off[0])
+        assert off[0] == len(buf), "bytes follow m_high_0_select"
     m = lbits // wl if wl else 0
     ibf = PlainIBF(bins, bsize, h)
     z = k_ = 0
@@ -319,4 +420,5 @@ def read_index(path):
             z += 1
         pos += 1
     return dict(w=w, k=k, max_fpr=fpr, num_bins=nb, categories=cats, filepath_to_bin=f2b, bin_to_category=b2c,
-                num_files=nfiles, records_per_bin=rpb, hashes_per_bin=hpb, hash_shift=shift, ibf=ibf, msize=msize)
+                num_files=nfiles, records_per_bin=rpb, hashes_per_bin=hpb, hash_shift=shift, ibf=ibf, msize=msize,
+                high=high, high_bits=hbits, select1=select1, select0=select0)

@@ -8,6 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
+from oracle import pyref
 from tests import util
 
 pytestmark = pytest.mark.gpu
@@ -249,6 +250,20 @@ def test_cli_index_builds_the_same_index_as_the_oracle(tmp_path, oracle_lib):
     assert (got.k, got.w, got.bins, got.bin_size, got.hash_funs) == (want.k, want.w, want.bins, want.bin_size, want.hash_funs)
     assert list(got.bin_to_cat) == list(want.bin_to_cat)
     assert np.array_equal(got.words(), want.words())
+    # the file closes with the sd_vector's two select_support_mcl blocks (what upstream's archive(ibf_) stores): the oracle's loader answers
+    # select from them, and they are, byte for byte, what the oracle's statement-by-statement restatement of sdsl writes for this m_high
+    L = oracle_lib.lib()
+    assert L.orc_sd_has_select(got.h) == 1
+    meta = pyref.read_index(str(tmp_path / "built.idx"))
+    hb = pyref.bit_array(meta["high"], meta["high_bits"])
+    for b, d in ((1, meta["select1"]), (0, meta["select0"])):
+        pos = np.flatnonzero(hb == b)
+        assert d["arg_cnt"] == len(pos) == L.orc_sd_select_args(got.h, b)
+        for i in (1, 2, 64, 65, 4096, 4097, len(pos) // 2, len(pos)):
+            assert pyref.select_from_blocks(d, hb, b, i) == int(pos[i - 1]) == L.orc_sd_select(got.h, b, i)
+    words = np.packbits(np.concatenate([hb, np.zeros((-len(hb)) % 64, np.uint8)]), bitorder="little").view(np.uint64)
+    tail = oracle_lib.select_blocks(words, len(hb), str(tmp_path / "tail.bin"))
+    assert open(tmp_path / "built.idx", "rb").read().endswith(tail) and len(tail) > 100
     # chromosome-sized records are processed in overlapping pieces; force tiny pieces to exercise that path -- and build on five
     # threads (several-thread sort of the minimiser sets, Elias-Fano arrays written by all threads at once): the same file, byte for byte
     p2 = subprocess.run([EXE, "index", "-t", "5", "-p", str(tmp_path / "pieces"), "--log", str(tmp_path / "i.log"), str(tab)], stdout=subprocess.PIPE,
@@ -294,7 +309,7 @@ def test_cli_rejects_corrupted_index_payload(tmp_path):
     after decode), never classified with"""
     fq = os.path.join(G, "cfg1_reads.fastq.gz")
     src = open(os.path.join(G, "cfg1.idx"), "rb").read()
-    n = len(src)
+    n = os.path.getsize(os.path.join(G, "cfg1_no_select.idx"))  # the same file up to the end of m_high
     outcomes = []
     for where, mask in ((n - 9, 0xFF), (n - 2000, 0x10), (n // 2, 0x01), (n // 2 + 777, 0x80)):
         b = bytearray(src)
@@ -308,6 +323,29 @@ def test_cli_rejects_corrupted_index_payload(tmp_path):
     assert any(rc != 0 for rc, _ in outcomes), outcomes
     for rc, msg in outcomes:
         assert rc != 0 or "self-check" in open(tmp_path / "charon.log").read(), outcomes
+
+
+def test_cli_index_select_blocks_checked_on_load(tmp_path):
+    """a file that carries the sd_vector's two select_support_mcl blocks (upstream's layout) has them verified against
+    m_high on load; damage there is an error with a file offset; a file of an earlier build of this program (ends behind m_high) still loads"""
+    fq = os.path.join(G, "cfg1_reads.fastq.gz")
+    want = open(os.path.join(G, "cfg1_expected.tsv")).read()
+    rc, out, err = run_cli(["--db", os.path.join(G, "cfg1.idx"), fq], str(tmp_path))
+    assert rc == 0, err
+    assert_same_tsv(out, want)
+    assert "select_support_mcl blocks answer select exactly as m_high does" in open(tmp_path / "charon.log").read()
+    rc, out, err = run_cli(["--db", os.path.join(G, "cfg1_no_select.idx"), fq], str(tmp_path))
+    assert rc == 0, err
+    assert_same_tsv(out, want)
+    assert "ends behind m_high" in open(tmp_path / "charon.log").read()
+    src = open(os.path.join(G, "cfg1.idx"), "rb").read()
+    n0 = os.path.getsize(os.path.join(G, "cfg1_no_select.idx"))
+    for what, buf in (("arg_cnt", src[:n0] + bytes([src[n0] ^ 1]) + src[n0 + 1:]), ("stored answer", src[:n0 + 41] + bytes([src[n0 + 41] ^ 4]) + src[n0 + 42:]),
+                      ("truncated", src[:-5]), ("trailing bytes", src + b"\0\0\0")):
+        p = tmp_path / "bad.idx"
+        p.write_bytes(buf)
+        rc, out, err = run_cli(["--db", str(p), fq], str(tmp_path))
+        assert rc != 0 and out == "" and "select_support_mcl" in err and "file offset" in err, (what, err)
 
 
 def test_cli_long_reads_compression_column(tmp_path, oracle_lib):
