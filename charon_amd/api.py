@@ -252,9 +252,12 @@ def default_model(num_categories, host_index, paired=False, dist="kde", pos_para
 
 
 class Stream:
-    def __init__(self, index, max_reads, max_bases, profile=False, tiny_log=False):
+    def __init__(self, index, max_reads, max_bases, profile=False, tiny_log=False, split_bucket=0):
+        """split_bucket (testing): length class from which single-end reads are cut over the 64 lanes of a wavefront
+        (CHN_STREAM_SPLIT_BUCKET: 0 = default, 32 768 bases; 64 = 1 024 bases; 255 = never)"""
         self.index = index
-        cfg = StreamCfg(C.sizeof(StreamCfg), (STREAM_PROFILE if profile else 0) | (STREAM_TINY_LOG if tiny_log else 0), max_reads, max_bases)
+        cfg = StreamCfg(C.sizeof(StreamCfg), (STREAM_PROFILE if profile else 0) | (STREAM_TINY_LOG if tiny_log else 0) | ((split_bucket & 0xff) << 8),
+                        max_reads, max_bases)
         self.h = C.c_void_p()
         _chk(_L.chn_stream_create(index.h, C.byref(cfg), C.byref(self.h)))
         self.C = index.desc.num_categories

@@ -142,6 +142,11 @@ typedef struct chn_stream_cfg {
 #define CHN_STREAM_PROFILE 1u   /* bracket every kernel with HIP events (chn_stream_profile) */
 #define CHN_STREAM_TINY_LOG 2u  /* testing only: start with a deliberately undersized row log so that every batch takes the
                                  * overflow -> worst-case re-run path of chn_batch_wait */
+/* A single-end read of 32 768 bases or more is rolled by the 64 lanes of one wavefront at once, in pieces that overlap by w - 1
+ * bases (exact: a piece starts only where the window minimum is unique); shorter reads take one lane each.  Testing only:
+ * CHN_STREAM_SPLIT_BUCKET(b) moves that limit to length class b (8 classes per octave: class = 8 (floor(log2 L) - 2) + the three
+ * bits below L's leading one; 64 = 1 024 bases, the smallest accepted; 104 = the default; 255 = never split). */
+#define CHN_STREAM_SPLIT_BUCKET(b) (((uint32_t)(b) & 0xffu) << 8)
 
 int chn_stream_create(chn_index *idx, const chn_stream_cfg *cfg, chn_stream **out);
 int chn_stream_destroy(chn_stream *s);
