@@ -335,6 +335,12 @@ def main():
     if use_dist and not rows_mode:  # in rows mode every rank already holds the calls of the whole batch
         summary = shard.merge_summary(summary, dist, coll_dev)
 
+    ranks_seen = 1
+    if use_dist:  # every rank that reached this point counts itself
+        t = torch.ones(1, dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ranks_seen = int(t.item())
+
     k1_ms, k1_n = stream.profile(0)
     k2_ms, k2_n = stream.profile(1)
     k3_ms, k3_n = stream.profile(2)
@@ -409,7 +415,7 @@ def main():
                                        "%d batches in flight" % (n_sets, max(1, min(args.inflight, 3))),
                        "ms_per_step_without_kernel_events": ms_no_events,
                        "reads_per_step_per_gpu": n_reads, "read_len": L, "read_len_max": Lmax, "bases_per_step_per_gpu": int(last_reads.n_bases),
-                       "index_bytes": S * ((B + 63) // 64) * 8,
+                       "index_bytes": S * ((B + 63) // 64) * 8, "ranks_seen": ranks_seen,
                        "sharding": ("index rows sharded over ranks, same batch on every rank, one sum all-reduce of probe words per batch" if rows_mode else
                                     "index rows AND reads sharded over ranks; per batch one all-to-all of 4-byte row queries and one of the row words back" if sparse_mode else
                                     "reads sharded over ranks, full index replica per GPU, no data-path collective"),

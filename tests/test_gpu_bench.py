@@ -60,3 +60,21 @@ def test_bench_small_paired_batches_report_the_step_without_kernel_events():
     ne = d["config"]["ms_per_step_without_kernel_events"]
     assert ne is not None and 0 < ne <= d["ms_per_step"] * 1.25
     assert d["roofline"]["avg_launch_ms"] <= ne * 1.05  # launches collapsed: the step is the probe kernel plus a few per cent
+
+
+def test_two_ranks_drive_the_sharded_hip_paths_under_a_real_collective():
+    """The N > 1 code paths with the DEVICE in them: bench.py --gpus 2 starts two ranks (torch.distributed.run, gloo,
+    both on this box's one GPU -- a rehearsal, labelled so, never a scaling figure).  reads: replicas + the summary all-reduce; rows: the
+    sparse exchange (chn_shardx_* under two real all_to_all_v's: queries out, row words back); rows-dense: one sum all-reduce of probe
+    words.  Each must classify the same global reads as ONE rank does and arrive at the same summary counters (include/result.hpp:18-25)."""
+    common = ("--workload", "small", "--steps", "2", "--warmup", "1", "--read-sets", "1", "--no-cpu-baseline", "--no-pcie")
+    n = 4096
+    one_2n = _bench("--reads-per-step", str(2 * n), base=common)["config"]["summary_counts"]   # global reads [0, 2n)
+    one_n = _bench("--reads-per-step", str(n), base=common)["config"]["summary_counts"]        # global reads [0, n)
+    assert sum(one_2n.values()) == 2 * n and sum(one_n.values()) == n and min(one_n.values()) > 0
+    for mode, want in (("reads", one_2n), ("rows", one_2n), ("rows-dense", one_n)):
+        d = _bench("--gpus", "2", "--backend", "gloo", "--shard", mode, "--reads-per-step", str(n), base=common)
+        assert d.get("rehearsal") is True and d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2, (mode, d)
+        assert d["config"]["summary_counts"] == want, (mode, d["config"]["summary_counts"], want)
+        assert d["scaling"] == ("strong" if mode == "rows-dense" else "weak")
+        assert d["value"] > 0 and d["config"]["row_log_reruns"] == 0
