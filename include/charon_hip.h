@@ -202,8 +202,11 @@ typedef struct chn_batch {
  * proportions are not returned: they are float(count)/float(num_hashes) (:140-150), recomputed by the caller.
  * `flags` bit 0: a probability comparison that decides `call` was closer than 2e-6 relative (or a probability sits at the
  * float underflow edge of the `prob == 0` test of call_category), so the host should re-evaluate that read with its own
- * libm (the device exp() may differ from glibc in the last ulp).  chn_batch_wait does that itself for host batches with
- * host result buffers; with on_device results the flags are only reported. */
+ * libm (the device exp() may differ from glibc in the last ulp; 2e-4 for gamma / beta models, whose densities the device forms from a
+ * double log-density while the reference evaluates them in float: device-resident probabilities then agree to ~1e-5 only).
+ * chn_batch_wait does that itself for host batches with host result buffers -- for gamma / beta it re-evaluates every read in float --;
+ * with on_device results the flags are only reported and NOTHING is re-evaluated: a caller that needs the reference's `call` on
+ * flagged reads runs chn_classify_counts on their counts. */
 typedef struct chn_result {
     uint32_t struct_size;
     uint32_t on_device;        /* 0: pointers below are host buffers to fill; 1: receive device pointers */

@@ -698,6 +698,46 @@ def test_sparse_row_sharded_exchange_equals_replica_mode(api, oracle_lib):
         oidx.free()
 
 
+def test_sparse_exchange_with_mismatched_splits_is_an_error(api, oracle_lib):
+    """a query that names a row its owner does not hold (queries built from other row_splits than the shards', or delivered to
+    the wrong owner) is answered with row 0 by k_shx_serve; the batch in flight on the serving stream must then fail, not return counts."""
+    from charon_amd import pack
+    r = util.rng(43)
+    gs = [util.random_seq(r, 2500) for _ in range(2)]
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [0, 1], ["host", "microbial"], bin_size=30011)
+    reads = util.sample_reads(r, gs, 200, (200, 1500))
+    S, Wd = oidx.bin_size, oidx.bin_words
+    words = oidx.words()
+    shards = []
+    for lo, hi in ((0, S // 3), (S // 3, S)):
+        sh = api.Index(api.make_desc(oidx.bins, S, oidx.bin_to_cat, 2, 0, row_begin=lo, row_end=hi))
+        sh.upload(words[lo * Wd:hi * Wd], row_begin=lo)
+        shards.append(sh)
+    p = pack.pack_reads(reads)
+    st = api.Stream(shards[0], len(reads), p["n_bases"])
+    st.set_model(api.default_model(2, 0))
+    st.shardx_minimise_host(p, np.full(len(reads), 40.0, np.float32), np.zeros(len(reads), np.float32))
+    wrong = [0, S // 2, S]                      # not the shards' splits
+    n_probes, counts = st.shardx_counts(wrong)
+    dq = api.device_malloc(0, max(n_probes, 1) * 4)
+    st.shardx_queries(dq, n_probes)
+    st.sync()
+    q = api.device_download(0, dq, n_probes * 4, np.uint32)
+    assert (q[:counts[0]] >= S // 3).any()      # group 0 names rows beyond shard 0
+    d_out = api.device_malloc(0, max(n_probes, 1) * Wd * 8)
+    st.shardx_serve(shards[0], dq, counts[0], d_out)
+    st.shardx_serve(shards[1], dq + 4 * counts[0], counts[1], d_out + 8 * Wd * counts[0])
+    st.shardx_finish(d_out)
+    with pytest.raises(RuntimeError, match="rows this shard does not hold"):
+        st.wait_host()
+    api.device_free(0, dq)
+    api.device_free(0, d_out)
+    st.destroy()
+    for sh in shards:
+        sh.destroy()
+    oidx.free()
+
+
 def test_gamma_and_beta_models_call_category(api, oracle_lib):
     """`charon classify` / `--dist gamma|beta`: the parametric densities (include/classify_stats.hpp:377-381) in k_model_call, with
     the classify thresholds (include/classify_arguments.hpp:19-29) and call_category, against the oracle; also a moved neg
