@@ -346,6 +346,7 @@ def main():
     k3_ms, k3_n = stream.profile(2)
     chain_ms, chain_n = stream.profile(3)
     _, reruns = stream.profile(4)
+    _, fetches = stream.profile(5)   # row fetches the last batch's probe kernel issued
     alg_bytes, total_min = stream.last_batch_bytes()
     flags = api.device_download(local, res.flags, n_reads, np.uint8)
 
@@ -384,7 +385,7 @@ def main():
     # what the chip gives the bare probe pattern on this index, measured now (a few ms): the honest ceiling of the probe kernel
     gather_roof = None
     if not rows_mode and not sparse_mode:
-        k1_rate = (total_min * index.desc.hash_funs / (k1_ms / max(k1_n, 1) * 1e-3)) if k1_ms > 0 else 0.0
+        k1_rate = (fetches / (k1_ms / max(k1_n, 1) * 1e-3)) if k1_ms > 0 else 0.0
         roof = {pol: index.gather_roof(nt=(pol == "nt")) for pol in ("default", "nt")}
         best = max(roof.values())
         gather_roof = {"default_policy_fetches_per_s": roof["default"], "nt_policy_fetches_per_s": roof["nt"],
@@ -427,7 +428,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic["traffic_bytes"] if traffic else None,
                          "traffic_source": traffic["source"] if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_avg,
-                         "gathers_per_s": (total_min * index.desc.hash_funs / (k1_avg * 1e-3)) if k1_avg > 0 else 0.0,
+                         "gathers_per_s": (fetches / (k1_avg * 1e-3)) if k1_avg > 0 else 0.0,
+                         "gathers_issued_per_launch": int(fetches), "gathers_nominal_per_launch": int(total_min * index.desc.hash_funs),
                          "gather_roof": gather_roof,
                          "note": "HBM-bound on random row probes: each probe uses 8*W bytes of a 128-byte line, so traffic/algorithmic ~ 8x is "
                                  "line granularity, not re-reads; gather_roof is the rate THIS device gave, in this run, for nothing but uniformly "
@@ -548,20 +550,26 @@ def cpu_baseline(api, index, reads, res, n_reads, args, device, categories, b2c)
         rc = api.lib().chn_index_download_rows(index.h, r0, nr, words[r0 * d.bin_words:].ctypes.data)
         if rc != 0:
             raise RuntimeError("index download failed")
-    # the reference's -t is a uint8 (<= 255); a 1-GPU box gives this job a 16-CPU share, so use the affinity mask, capped
-    threads = max(1, min(len(os.sched_getaffinity(0)), 64))
-    sample = args.cpu_sample_reads or 4096
+    # Threads: what this job may really use -- min(cgroup CPU quota, affinity mask), capped at the reference's uint8 -t (255;
+    # src/dehost_main.cpp:341 num_threads(opt.threads)).  Reported field by field so that a reader can tell a 256-thread host from a 16-core share.
+    host = host_cpu_info()
+    threads = host["cores"]
+    sample = args.cpu_sample_reads or 32768
     sample = min(sample, n_reads)
     lens = api.device_download(device, reads.seg1_length, sample * 4, np.uint32)
     offs = api.device_download(device, reads.seg1_offset, sample * 8, np.uint64)
     nb = int(offs[-1] + ((int(lens[-1]) + 63) // 64) * 64)
     seqs = pack.unpack_reads(api.device_download(device, reads.bases2, nb // 4, np.uint32), offs, lens)
     cat, o = b"".join(seqs), np.concatenate([[0], np.cumsum(lens.astype(np.uint64))]).astype(np.uint64)
-    # calibrate on 256 reads, then size the timed sample to ~15 s
+    # calibrate on 256 reads, size the timed sample to ~3 s (at most the sample), then time it FIVE times: median + spread
     r = oidx.process_reads(cat[:int(o[256])] if sample > 256 else cat, o[:257] if sample > 256 else o, threads=threads)
     rate = min(256, sample) / max(r["seconds"], 1e-6)
-    n_timed = int(min(sample, max(256, rate * 15)))
-    r = oidx.process_reads(cat[:int(o[n_timed])], o[:n_timed + 1], threads=threads)
+    n_timed = int(min(sample, max(256, rate * 3)))
+    runs = []
+    for _ in range(5):
+        r = oidx.process_reads(cat[:int(o[n_timed])], o[:n_timed + 1], threads=threads)
+        runs.append(n_timed / r["seconds"])
+    runs.sort()
     gpu_call = api.device_download(device, res.call, n_reads, np.uint8)[:n_timed]
     gpu_nh = api.device_download(device, res.num_hashes, n_reads * 4, np.uint32)[:n_timed]
     gpu_cnt = api.device_download(device, res.counts, n_reads * 8, np.uint32).reshape(-1, 2)[:n_timed]
@@ -570,22 +578,22 @@ def cpu_baseline(api, index, reads, res, n_reads, args, device, categories, b2c)
                   np.array_equal(gpu_cnt, r["counts"]) and np.array_equal(gpu_unq, r["unique"]))
     # the reference's loop also gzips every read for its `compression` column (src/utils.cpp:114-124): same port with that
     # column switched on, on a smaller sample (reported beside the hot-path-only figure, not instead of it)
-    n_gz = n_timed
+    n_gz = min(n_timed, 8192)
     thr = po.default_thresholds(with_gzip=True)
     rg = oidx.process_reads(cat[:int(o[n_gz])], o[:n_gz + 1], threads=threads, thr=thr)
     # reference-faithful form: Elias-Fano get_int probes as the reference keeps the IBF compressed, per-read gzip,
     # at -t 1 and -t N.  The oracle builds its sd_vector straight from the downloaded plain words, in parallel (39 GB plain ->
     # ~35 GB compressed, next to the plain copy in host memory).
     faithful = None
-    # building the sd_vector of a 39 GB index takes ~40 s on 64 host threads; with a small CPU share it would dominate the run
-    if d.bin_size * d.bin_words * 8 <= (2 << 30) or (d.bin_size * d.bin_words * 8 <= (64 << 30) and threads >= 32):
+    # building the sd_vector of a 39 GB index takes ~40 s on a 16-core share; with a smaller one it would dominate the run
+    if d.bin_size * d.bin_words * 8 <= (2 << 30) or (d.bin_size * d.bin_words * 8 <= (64 << 30) and threads >= 16):
         t0 = time.perf_counter()
         oidx.compress()
         oidx.use_ef(True)
         t_build = time.perf_counter() - t0
-        n1 = min(n_timed, 256)
+        n1 = min(n_timed, 2048)   # (the -t 1 figure from at least 2 000 reads)
         r1 = oidx.process_reads(cat[:int(o[n1])], o[:n1 + 1], threads=1, thr=thr)
-        nN = min(n_timed, max(256, int(n1 / max(r1["seconds"], 1e-6) * threads * 4)))
+        nN = min(n_timed, max(2048, int(n1 / max(r1["seconds"], 1e-6) * threads * 3)))
         rN = oidx.process_reads(cat[:int(o[nN])], o[:nN + 1], threads=threads, thr=thr)
         ok = bool(np.array_equal(gpu_call[:nN], rN["call"]) and np.array_equal(gpu_nh[:nN], rN["num_hashes"]) and
                   np.array_equal(gpu_cnt[:nN], rN["counts"]) and np.array_equal(gpu_unq[:nN], rN["unique"]))
@@ -594,11 +602,44 @@ def cpu_baseline(api, index, reads, res, n_reads, args, device, categories, b2c)
                               "reference's loop has (restatement of the reference CPU path, not the reference)" % (n1, nN, threads),
                     "ef_build_seconds": round(t_build, 1), "gpu_parity_on_sample": ok}
     oidx.free()
-    return {"value": n_timed / r["seconds"], "unit": "reads/s", "cores": threads, "kind": "port",
+    return {"value": runs[len(runs) // 2], "unit": "reads/s", "cores": threads, "kind": "port",
+            "threads": threads, "cpus_allowed": host["cpus_allowed"], "cgroup_cpu_quota": host["cgroup_cpu_quota"], "cpu_model": host["cpu_model"],
+            "host_logical_cpus": host["logical_cpus"],
+            "runs": len(runs), "value_min": runs[0], "value_max": runs[-1], "spread": (runs[-1] - runs[0]) / runs[len(runs) // 2],
             "value_with_gzip_column": n_gz / rg["seconds"], "reference_faithful_form": faithful,
-            "sample": "%d of the same 5 kb reads vs the same index (downloaded from HBM), oracle hot path only: minimisers + "
-                      "plain-word IBF probes + counts + KDE + call, OpenMP over reads, no per-read gzip column" % n_timed,
+            "sample": "%d of the same reads vs the same index (downloaded from HBM), timed %d times (value = median), oracle hot path only: "
+                      "minimisers + plain-word IBF probes + counts + KDE + call, OpenMP over reads on %d threads, no per-read gzip column"
+                      % (n_timed, len(runs), threads),
             "gpu_parity_on_sample": parity}
+
+
+def host_cpu_info():
+    """what the CPU side of this job may use: affinity mask, cgroup CPU quota (v2 cpu.max, v1 cfs quota), CPU model; cores = the smaller of
+    the first two, capped at 255 (the reference's -t is a uint8)"""
+    allowed = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    cores = allowed if quota is None else max(1, min(allowed, int(quota + 0.5)))
+    return {"cpus_allowed": allowed, "cgroup_cpu_quota": quota, "cpu_model": model, "logical_cpus": os.cpu_count(), "cores": max(1, min(cores, 255))}
 
 
 if __name__ == "__main__":

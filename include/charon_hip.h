@@ -295,7 +295,9 @@ int chn_index_emplace(chn_index *idx, const uint64_t *host_values, uint64_t n_va
 
 /* Per-kernel device time accumulated since the last reset (CHN_STREAM_PROFILE streams only).
  * which: 0 = minimise+probe kernel, 1 = count kernel, 2 = model+call kernel, 3 = whole batch chain;
- * 4 (any stream): *launches = number of batches chn_batch_wait re-ran on worst-case buffers after a row-log overflow. */
+ * 4 (any stream): *launches = number of batches chn_batch_wait re-ran on worst-case buffers after a row-log overflow;
+ * 5 (any stream): *launches = row fetches the last waited batch's minimise+probe kernel issued (h per minimiser; fewer for an index of
+ *   at most four bins, whose rows are fetched one at a time and only while the AND so far still has a bin set). */
 int chn_stream_profile(chn_stream *s, int which, double *total_ms, uint64_t *launches, int reset);
 /* Algorithmic bytes of the last batch by SURVEY 8(d): sum over reads of ceil(L/4) + M*h*W*8 + (8 + 8C). */
 int chn_stream_last_batch_bytes(chn_stream *s, uint64_t *bytes, uint64_t *total_minimisers);

@@ -41,6 +41,12 @@ def test_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["gpu_parity_on_sample"] is True
+    # a stated, repeatable baseline: what the job may use (affinity, cgroup quota), the threads it did use, several timed runs
+    for k in ("threads", "cpus_allowed", "cgroup_cpu_quota", "cpu_model", "runs", "value_min", "value_max", "spread"):
+        assert k in c, k
+    assert c["threads"] == c["cores"] <= c["cpus_allowed"] and c["runs"] >= 3 and c["value_min"] <= c["value"] <= c["value_max"]
+    # the probe kernel reports the row fetches it issued: all h per minimiser, or fewer for this 2-bin index (one row at a time while the AND lives)
+    assert 0 < r["gathers_issued_per_launch"] < r["gathers_nominal_per_launch"]
     # sub-millisecond steps are also timed without kernel events, and that figure cannot exceed the one with them by much
     ne = d["config"]["ms_per_step_without_kernel_events"]
     assert ne is None or 0 < ne <= d["ms_per_step"] * 1.25
