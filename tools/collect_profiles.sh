@@ -3,7 +3,7 @@
 # judged into profiles/rNN afterwards):  bash tools/collect_profiles.sh r02 <commit>
 set -e
 export TMPDIR=/tmp
-R=${1:-r02}
+R=${1:-r03}
 COMMIT=${2:-unknown}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/prof_$R
@@ -33,7 +33,7 @@ with open(out + "/pmc_summary.csv", "w") as f:
     for k, cs in agg.items():
         for c, (n, v) in cs.items():
             f.write("%s,%s,%d,%.1f\n" % (k, c, n, v / n))
-k1 = [k for k in agg if "k_minimise_probe<2, 1, 23>" in k][0]
+k1 = [k for k in agg if "k_minimise_probe<2, 1, 23, false" in k or "k_minimise_probe<2, 1, 23>" in k][0]  # the ordinary launch of the W = 2 row-log kernel
 fetch_kb, write_kb = agg[k1]["FETCH_SIZE"][1] / agg[k1]["FETCH_SIZE"][0], agg[k1]["WRITE_SIZE"][1] / agg[k1]["WRITE_SIZE"][0]
 traffic = fetch_kb * 1024 * 2 + write_kb * 1024   # gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes
 json.dump({"commit": commit, "date": datetime.date.today().isoformat(),
@@ -64,11 +64,22 @@ for f in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
     except Exception as e:
         print(os.path.basename(f), "failed", e)
 PY
+# 5b. two ranks on this one GPU (gloo rehearsal of the N > 1 paths at the 39 GB shape: plumbing + summary counters, never a scaling figure)
+for mode in reads rows; do
+  python3 bench.py --gpus 2 --backend gloo --workload 39g --shard $mode --steps 4 --warmup 1 --read-sets 1 --no-cpu-baseline --no-pcie > $OUT/rehearsal_2ranks_$mode.json 2>$OUT/rehearsal_2ranks_$mode.err || true
+done
+python3 bench.py --workload 39g --steps 4 --warmup 1 --read-sets 1 --reads-per-step 2097152 --no-cpu-baseline --no-pcie > $OUT/rehearsal_1rank_2n.json 2>/dev/null || true
+# 5c. SQ counters of the probe kernel (issue vs wait)
+WORKLOAD=39g KERNEL="k_minimise_probe<2, 1, 23, false" bash $ROOT/tools/k1_sq_pmc.sh > $OUT/sq_39g.txt 2>&1 || true
+WORKLOAD=cfg2 KERNEL="k_minimise_probe<1, 0, 23, false" bash $ROOT/tools/k1_sq_pmc.sh > $OUT/sq_cfg2.txt 2>&1 || true
 # 6. the CLI: phase timers + per-kernel GPU time of one run, throughput table, compressed inputs
 bash $ROOT/tools/cli_phase_run.sh 400000 > /dev/null 2>&1 || true
 cp $ROOT/gpurun_out/cli_phase/phase.txt $OUT/cli_phase.txt 2>/dev/null || true
 cp $ROOT/gpurun_out/cli_phase/kernel_stats_cli.csv $OUT/kernel_stats_cli.csv 2>/dev/null || true
 python3 $ROOT/tools/cli_throughput.py 400000 /tmp/clib > $OUT/cli_throughput_raw.txt 2>&1 || true
+rm -rf /tmp/clib /tmp/clip
+python3 $ROOT/tools/cli_steady_state.py 4000000 /tmp/css 16 16 1 > $OUT/cli_steady_state.txt 2>&1 || true
+rm -rf /tmp/css
 bash $ROOT/tools/cli_gz_run.sh 100000 > /dev/null 2>&1 || true
 cp $ROOT/gpurun_out/cli_gz.txt $OUT/cli_gz.txt 2>/dev/null || true
 ./tools/h2d_bench > $OUT/h2d_microbench.txt 2>&1 || true
