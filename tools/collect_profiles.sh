@@ -65,10 +65,11 @@ for f in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
         print(os.path.basename(f), "failed", e)
 PY
 # 5b. two ranks on this one GPU (gloo rehearsal of the N > 1 paths at the 39 GB shape: plumbing + summary counters, never a scaling figure)
+# (both ranks share ONE 288 GB card here: 2 x 262 144 reads per step, so that two sets of exchange buffers fit beside the two index halves / replicas)
 for mode in reads rows; do
-  python3 bench.py --gpus 2 --backend gloo --workload 39g --shard $mode --steps 4 --warmup 1 --read-sets 1 --no-cpu-baseline --no-pcie > $OUT/rehearsal_2ranks_$mode.json 2>$OUT/rehearsal_2ranks_$mode.err || true
+  python3 bench.py --gpus 2 --backend gloo --workload 39g --shard $mode --steps 4 --warmup 1 --read-sets 1 --reads-per-step 262144 --no-cpu-baseline --no-pcie > $OUT/rehearsal_2ranks_$mode.json 2>$OUT/rehearsal_2ranks_$mode.err || true
 done
-python3 bench.py --workload 39g --steps 4 --warmup 1 --read-sets 1 --reads-per-step 2097152 --no-cpu-baseline --no-pcie > $OUT/rehearsal_1rank_2n.json 2>/dev/null || true
+python3 bench.py --workload 39g --steps 4 --warmup 1 --read-sets 1 --reads-per-step 524288 --no-cpu-baseline --no-pcie > $OUT/rehearsal_1rank_2n.json 2>/dev/null || true
 # 5c. SQ counters of the probe kernel (issue vs wait)
 WORKLOAD=39g KERNEL="k_minimise_probe<2, 1, 23, false" bash $ROOT/tools/k1_sq_pmc.sh > $OUT/sq_39g.txt 2>&1 || true
 WORKLOAD=cfg2 KERNEL="k_minimise_probe<1, 0, 23, false" bash $ROOT/tools/k1_sq_pmc.sh > $OUT/sq_cfg2.txt 2>&1 || true
