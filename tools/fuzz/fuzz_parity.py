@@ -56,6 +56,27 @@ def trial(r, t):
     reads = [spice(s) for s in reads]
     if mates:
         mates = [spice(s) for s in mates]
+    # long reads for the SPLIT launch (single-end): stitched from random sequence, genome slices, homopolymer runs and tandem repeats, so that
+    # piece seams fall into ties as well as into ordinary sequence
+    split_bucket = int(r.choice([0, 64, 64, 72, 88, 255]))
+    if not paired and r.random() < 0.5:
+        for _ in range(int(r.integers(1, 6))):
+            total, parts = int(r.integers(1000, 150000)), []
+            while sum(map(len, parts)) < total:
+                kind, L = int(r.integers(0, 4)), int(r.integers(50, 20000))
+                if kind == 0:
+                    parts.append(util.random_seq(r, L))
+                elif kind == 1:
+                    g = gs[int(r.integers(0, len(gs)))]
+                    s0 = int(r.integers(0, max(1, len(g) - 1)))
+                    parts.append(util.mutate(r, g[s0:s0 + L], 0.03))
+                elif kind == 2:
+                    parts.append(bytes([b"ACGTN"[int(r.integers(0, 5))]]) * min(L, 3000))
+                else:
+                    unit = util.random_seq(r, int(r.integers(1, 13)))
+                    parts.append((unit * (min(L, 4000) // len(unit) + 1))[:min(L, 4000)])
+            reads[int(r.integers(0, len(reads)))] = b"".join(parts)[:total]
+        n = len(reads)
     if not any(len(s) for s in reads):
         reads[0] = b"ACGT" * 20
     if r.random() < 0.2:
@@ -65,18 +86,24 @@ def trial(r, t):
     g = util.gpu_index_from_oracle(api, oidx)
     try:
         p = pack.pack_reads(reads, mates)
-        st = api.Stream(g, max(n, 1), p["n_bases"])
+        tiny = bool(r.random() < 0.15)
+        st = api.Stream(g, max(n, 1), p["n_bases"], tiny_log=tiny, split_bucket=split_bucket)
         st.set_model(api.default_model(C, oidx.host_index if not paired else 0, paired=paired))
-        st.submit_host(p, np.full(n, 40.0, np.float32), np.zeros(n, np.float32))
-        gpu = st.wait_host()
+        twice = bool(r.random() < 0.3)
+        for _ in range(2 if twice else 1):
+            st.submit_host(p, np.full(n, 40.0, np.float32), np.zeros(n, np.float32))
+        outs = [st.wait_host() for _ in range(2 if twice else 1)]
+        gpu = outs[0]
         st.destroy()
         seqs, offs, split = util.concat(reads, mates)
         orc = oidx.process_reads(seqs, offs, mate_split=split, mq_const=40.0, threads=8)
-        util.assert_parity(gpu, orc)
+        for o in outs:
+            util.assert_parity(o, orc)
     finally:
         g.destroy()
         oidx.free()
-    return "k=%d w=%d B=%d C=%d h=%d S=%d n=%d lmax=%d paired=%d hashes=%d" % (k, w, B, C, h, bin_size, n, lmax, paired, int(gpu["num_hashes"].sum()))
+    return "k=%d w=%d B=%d C=%d h=%d S=%d n=%d lmax=%d longest=%d paired=%d split_bucket=%d tiny_log=%d hashes=%d" % (
+        k, w, B, C, h, bin_size, n, lmax, max(map(len, reads)), paired, split_bucket, tiny, int(gpu["num_hashes"].sum()))
 
 
 def sharded_trial(r, oidx, reads, mates, C, paired):
