@@ -1,5 +1,6 @@
 import os, random, subprocess, sys, struct
 random.seed(int(sys.argv[1]))
+TAIL = len(sys.argv) > 2 and sys.argv[2] == "tail"   # mutate only the sd_vector's two select_support_mcl blocks (the last 632 bytes of the fixture)
 EXE="/tmp/asan/charon"
 src=open("/root/repo/tests/golden/cfg1.idx","rb").read()
 open("/tmp/asan/w/r.fq","w").write("@a\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n+\n"+"I"*48+"\n")
@@ -10,6 +11,7 @@ for it in range(300):
     for _ in range(random.choice([1,1,2,4])):
         if len(b)<2: break
         p=random.randrange(min(len(b),400) if hdr else len(b))
+        if TAIL: p=random.randrange(max(0,len(b)-632),len(b))
         op=random.random()
         if op<0.4: b[p]=random.randrange(256)
         elif op<0.6: b[p:p+8]=struct.pack("<Q",random.choice([0,1,2**63,2**64-1,2**40,2**58,random.getrandbits(64)]))
