@@ -364,11 +364,12 @@ class Stream:
         self._shard = None
 
     def submit_device(self, n_reads, n_bases, bases2, seg1_offset, seg1_length, mean_quality=None, compression=None,
-                      nmask=None, seg2_offset=None, seg2_length=None):
+                      nmask=None, seg2_offset=None, seg2_length=None, gzip_tallies=0, gzip_output=0):
         b = Batch()
         b.struct_size, b.on_device, b.n_reads, b.n_bases = C.sizeof(Batch), 1, n_reads, n_bases
         b.bases2, b.nmask, b.seg1_offset, b.seg1_length = bases2, nmask, seg1_offset, seg1_length
         b.seg2_offset, b.seg2_length, b.mean_quality, b.compression = seg2_offset, seg2_length, mean_quality, compression
+        b.gzip_tallies, b.gzip_output = gzip_tallies, gzip_output
         _chk(_L.chn_batch_submit(self.h, C.byref(b)))
         self._fifo.append((n_reads, None))
 
