@@ -23,6 +23,7 @@ for v in "$@"; do
     pieces8) D="-DCHN_BASE_PIECES=8" ;;
     allprobes) D="-DK1_COND_MAX_BINS=0" ;;
     condall) D="-DK1_COND_MAX_BINS=255" ;;
+    k2big) D="-DK2_LDS_BUDGET=65536u" ;;
     *) D="-D$v" ;;
   esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++14 -ffp-contract=off -fPIC -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-but-set-variable -I$R/include -I$R/charon_amd/csrc $D -shared \
