@@ -870,32 +870,34 @@ def test_gzip_sizes_on_the_device_equal_zlib(api, oracle_lib):
         for _ in range(int(r.integers(0, 30))):
             s[int(r.integers(0, n))] = b"ACGT"[int(r.integers(0, 4))]
         reads.append(bytes(s))
-    p = pack.pack_reads(reads)
-    st = api.Stream(g, len(reads), p["n_bases"])
-    st.set_model(api.default_model(2, 0))
-    st.submit_host(p, np.full(len(reads), 40.0, np.float32), None, gzip_tallies=61440, gzip_output=2)
-    out = st.wait_host()
-    sizes, status = out["gzip_sizes"], out["gzip_tallies"][:, 316]
 
     def zsize(b):
         co = zlib.compressobj(6, zlib.DEFLATED, 31, 8)
         return len(co.compress(b) + co.flush())
-    on_device = 0
-    for i, rd in enumerate(reads):
-        if len(rd) > 61440:
-            assert status[i] != 0 and sizes[i] == 0
-            continue
-        if status[i] != 0:  # more than 16 382 symbols: a second deflate block -- only long reads with few matches may say so
-            assert len(rd) > 16383 * 3 // 2 and sizes[i] == 0, (i, len(rd))
-            continue
-        on_device += 1
-        assert int(sizes[i]) == zsize(rd), (i, len(rd), rd[:40])
-    assert on_device >= len(reads) - 6
-    # sizes only: no tallies come back, the same numbers do
-    st.submit_host(p, np.full(len(reads), 40.0, np.float32), None, gzip_tallies=61440, gzip_output=1)
-    out1 = st.wait_host()
-    assert "gzip_tallies" not in out1 and np.array_equal(out1["gzip_sizes"], sizes)
-    st.destroy()
+    # a batch without a single N takes the kernel's other form (codes of two bits, sixteen letters per comparison, no end mark in LDS)
+    for reads in (reads, [rd.replace(b"N", b"G") for rd in reads]):
+        p = pack.pack_reads(reads)
+        st = api.Stream(g, len(reads), p["n_bases"])
+        st.set_model(api.default_model(2, 0))
+        st.submit_host(p, np.full(len(reads), 40.0, np.float32), None, gzip_tallies=61440, gzip_output=2)
+        out = st.wait_host()
+        sizes, status = out["gzip_sizes"], out["gzip_tallies"][:, 316]
+        on_device = 0
+        for i, rd in enumerate(reads):
+            if len(rd) > 61440:
+                assert status[i] != 0 and sizes[i] == 0
+                continue
+            if status[i] != 0:  # more than 16 382 symbols: a second deflate block -- only long reads with few matches may say so
+                assert len(rd) > 16383 * 3 // 2 and sizes[i] == 0, (i, len(rd))
+                continue
+            on_device += 1
+            assert int(sizes[i]) == zsize(rd), (i, len(rd), rd[:40])
+        assert on_device >= len(reads) - 6
+        # sizes only: no tallies come back, the same numbers do
+        st.submit_host(p, np.full(len(reads), 40.0, np.float32), None, gzip_tallies=61440, gzip_output=1)
+        out1 = st.wait_host()
+        assert "gzip_tallies" not in out1 and np.array_equal(out1["gzip_sizes"], sizes)
+        st.destroy()
     g.destroy()
     oidx.free()
 

@@ -96,6 +96,10 @@ def main():
         if paired:
             reads = [x[:30000] for x in reads]
             mates = [make_read(r)[:30000] for _ in range(nreads)]
+        if r.random() < 0.5:  # a batch without N: the kernel's two-bit form
+            sub = bytes(r.choice(list(b"ACGT"), 1).astype(np.uint8))
+            reads = [x.replace(b"N", sub) for x in reads]
+            mates = [x.replace(b"N", sub) for x in mates] if paired else None
         p = pack.pack_reads(reads, mates) if paired else pack.pack_reads(reads)
         st = api.Stream(g, nreads, p["n_bases"])
         st.set_model(api.default_model(2, 0, paired=paired) if paired else api.default_model(2, 0))
