@@ -902,6 +902,44 @@ def test_gzip_sizes_on_the_device_equal_zlib(api, oracle_lib):
     oidx.free()
 
 
+def test_gzip_sizes_when_a_wavefront_takes_many_reads(api, oracle_lib):
+    """k_gzip_tally's wavefronts take read after read from a counter and re-use their scratch (class arrays in global memory) and LDS:
+    a batch of far more reads than the device holds wavefronts (8 192 on 256 CUs), every size against zlib"""
+    import zlib
+    from charon_amd import pack
+    r = util.rng(71)
+    gs = [util.random_seq(r, 4000), util.random_seq(r, 4000)]
+    oidx = util.build_oracle_index(oracle_lib, [[g] for g in gs], [0, 1], ["host", "microbial"])
+    g = util.gpu_index_from_oracle(api, oidx)
+    n = 40000
+    pool = util.random_seq(r, 200000)
+    starts, lens = r.integers(0, 199000, n), r.integers(1, 700, n)
+    reads = []
+    for i in range(n):
+        rd = pool[int(starts[i]):int(starts[i]) + int(lens[i])]
+        if i % 7 == 0:
+            rd = rd[:len(rd) // 2] * 2 + rd[:3]      # an internal copy: long matches
+        reads.append(rd)
+
+    def zsize(b):
+        co = zlib.compressobj(6, zlib.DEFLATED, 31, 8)
+        return len(co.compress(b) + co.flush())
+    for with_n in (False, True):  # both forms of the kernel (a batch with an N keeps four-bit codes)
+        if with_n:
+            reads[5] = reads[5][:10] + b"N" + reads[5][10:]
+        p = pack.pack_reads(reads)
+        st = api.Stream(g, n, p["n_bases"])
+        st.set_model(api.default_model(2, 0))
+        st.submit_host(p, np.full(n, 40.0, np.float32), None, gzip_tallies=61440, gzip_output=1)
+        sizes = st.wait_host()["gzip_sizes"]
+        st.destroy()
+        want = np.array([zsize(rd) for rd in reads], np.uint32)
+        bad = np.nonzero(sizes != want)[0]
+        assert bad.size == 0, (with_n, bad[:10], sizes[bad[:10]], want[bad[:10]])
+    g.destroy()
+    oidx.free()
+
+
 def test_gather_roof_is_a_plausible_rate(api, oracle_lib):
     """chn_index_gather_roof (what bench.py prices the probe kernel against): random row fetches per second of this device on this
     index -- a finite positive rate, the same order of magnitude for both cache policies (a toy index sits in the caches: far above the
