@@ -382,6 +382,26 @@ def main():
         for a in (packed["bases2"], packed["seg1_offset"], packed["seg1_length"], mqh, cph):
             api.host_free(a)
 
+    # informational (never `value`): the same device-resident batches with the gzip `compression` column ALSO computed on the device (deflate
+    # pass + tree arithmetic per read, src/utils.cpp:114-124) -- what the drop-in binary asks of the GPU per batch
+    gzip_rate = None
+    if not args.no_pcie and world == 1 and not paired and not rows_mode and not sparse_mode and Lmax <= 61440:
+        reads = last_reads
+        k_gz = 3
+
+        def gz_batch():
+            stream.submit_device(n_reads, reads.n_bases, reads.bases2, reads.seg1_offset, reads.seg1_length, reads.mean_quality, None,
+                                 gzip_tallies=Lmax, gzip_output=1)
+        gz_batch()
+        stream.wait_device()
+        t1 = time.perf_counter()
+        gz_batch()
+        for i in range(k_gz):
+            if i + 1 < k_gz:
+                gz_batch()
+            stream.wait_device()
+        gzip_rate = k_gz * n_reads / (time.perf_counter() - t1)
+
     # what the chip gives the bare probe pattern on this index, measured now (a few ms): the honest ceiling of the probe kernel
     gather_roof = None
     if not rows_mode and not sparse_mode:
@@ -423,6 +443,7 @@ def main():
                        "mean_minimisers_per_read": total_min / n_reads, "borderline_reads": int(flags.sum()), "row_log_reruns": int(reruns),
                        "summary_counts": dict([(categories[c], int(summary[c])) for c in range(ncat)] + [("unclassified", int(summary[ncat]))]),
                        "setup_seconds": round(setup_s, 1), "pcie_inclusive_reads_per_s": pcie_rate,
+                       "with_gzip_column_on_device_reads_per_s": gzip_rate,
                        "pcie_leg": None if pcie_rate is None else "20 batches through chn_batch_submit with pinned host buffers, three in flight; fill and drain inside the timed leg"},
             "roofline": {"bound": "hbm", "kernel": "k_minimise_probe", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic["traffic_bytes"] if traffic else None,
