@@ -200,7 +200,9 @@ class Index:
                                         elem0, ls.size, C.byref(bad)))
             bad_total += bad.value
             ones_before += ones
-        return bad_total
+        bad = C.c_uint64()  # the closing call: waits for the slices in flight and reports the ill-placed bits they met
+        _chk(_L.chn_index_decode_ef(self.h, m_size, wl, high.ctypes.data if high.size else np.zeros(1, np.uint64).ctypes.data, 0, 0, 0, None, 0, 0, C.byref(bad)))
+        return bad_total + bad.value
 
     def bin_popcounts(self):
         out = np.zeros(self.desc.technical_bins, np.uint64)

@@ -73,7 +73,12 @@ int chn_index_upload_rows(chn_index *idx, uint64_t row_begin, uint64_t n_rows, c
  * set bits of m_high before that slice (the caller keeps the running popcount); `low` holds the packed m_low elements starting
  * with element `low_elem0` <= ones_before, `n_low_words` words (the last partial word included).  Every one of the slice is turned
  * into its plain bit position ((zeros before it) << wl | low part) and set in the index words; positions outside this shard's
- * rows are skipped.  *bad_bits counts positions >= m_size or in technical bins >= bins (must stay 0 for a well-formed file). */
+ * rows are skipped.
+ * The slice's work is QUEUED: the call returns as soon as `high` and `low` have been read (page-locked memory: chn_host_alloc; the copy
+ * of pageable memory is what it waits for otherwise), so the caller prepares the next slice while the device decodes this one.
+ * A closing call with n_high_words == 0 waits for every slice in flight and sets *bad_bits to the number of positions >= m_size or in
+ * technical bins >= bins that the slices met (must be 0 for a well-formed file); calls with a slice set *bad_bits to 0.
+ * chn_index_bin_popcounts and chn_stream_create wait for the slices as well. */
 int chn_index_decode_ef(chn_index *idx, uint64_t m_size, uint32_t wl, const uint64_t *high, uint64_t high_bit0, uint64_t n_high_words,
                         uint64_t ones_before, const uint64_t *low, uint64_t low_elem0, uint64_t n_low_words, uint64_t *bad_bits);
 /* set bits per technical bin over the rows this object holds (loader self-check iv); out[technical_bins] */
