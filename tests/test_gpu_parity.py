@@ -579,6 +579,10 @@ def test_device_batches_bad_and_overlapping_segments(api, oracle_lib):
         st.submit_device(n, nb, d_bases, d_off, d_len)
         with pytest.raises(api.ChnError, match="misaligned or lies outside"):
             st.wait_device()
+        # the deflate pass checks its segments the same way (it must never read them)
+        st.submit_device(n, nb, d_bases, d_off, d_len, gzip_tallies=6000, gzip_output=1)
+        with pytest.raises(api.ChnError, match="misaligned or lies outside"):
+            st.wait_device()
     # the stream stays usable
     api.device_upload(0, d_off, offs)
     api.device_upload(0, d_len, lens)
