@@ -47,6 +47,8 @@ def test_bench_line_has_the_contract_fields():
     assert c["threads"] == c["cores"] <= c["cpus_allowed"] and c["runs"] >= 3 and c["value_min"] <= c["value"] <= c["value_max"]
     # the probe kernel reports the row fetches it issued: all h per minimiser, or fewer for this 2-bin index (one row at a time while the AND lives)
     assert 0 < r["gathers_issued_per_launch"] < r["gathers_nominal_per_launch"]
+    # informational legs beside `value`: the same batches through host buffers, and with the gzip column computed on the device as well
+    assert d["config"]["pcie_inclusive_reads_per_s"] > 0 and 0 < d["config"]["with_gzip_column_on_device_reads_per_s"] <= d["value"] * 1.05
     # sub-millisecond steps are also timed without kernel events, and that figure cannot exceed the one with them by much
     ne = d["config"]["ms_per_step_without_kernel_events"]
     assert ne is None or 0 < ne <= d["ms_per_step"] * 1.25
