@@ -338,6 +338,12 @@ def test_cli_index_select_blocks_checked_on_load(tmp_path):
     assert rc == 0, err
     assert_same_tsv(out, want)
     assert "ends behind m_high" in open(tmp_path / "charon.log").read()
+    # the loader's slices (an index of the published size goes over in some 600 of them, staged by the reader's threads while the device decodes
+    # the slice before): the fixture in slices of 1, 7 and 64 words of m_high -- the running count of ones and the m_low offsets across slices
+    for words in ("1", "7", "64"):
+        rc, out, err = run_cli(["--db", os.path.join(G, "cfg1.idx"), fq], str(tmp_path), {"CHARON_INDEX_SLICE": words})
+        assert rc == 0, (words, err)
+        assert_same_tsv(out, want)
     src = open(os.path.join(G, "cfg1.idx"), "rb").read()
     n0 = os.path.getsize(os.path.join(G, "cfg1_no_select.idx"))
     for what, buf in (("arg_cnt", src[:n0] + bytes([src[n0] ^ 1]) + src[n0 + 1:]), ("stored answer", src[:n0 + 41] + bytes([src[n0 + 41] ^ 4]) + src[n0 + 42:]),
