@@ -434,7 +434,7 @@ def test_hash_function_counts_and_long_windows(api, oracle_lib):
 
 
 @pytest.mark.parametrize("bins,bin_size,ones,slice_words", [(100, 5000, 60000, 64), (8, 70001, 300000, 1000), (130, 997, 1, 1 << 20),
-                                                            (3, 4096, 200000, 7)])
+                                                            (3, 4096, 200000, 7), (200, 3001, 150000, 33)])
 def test_device_elias_fano_decode(api, bins, bin_size, ones, slice_words):
     """chn_index_decode_ef (loader): sd_vector low/high arrays -> plain rows on the device, sliced; checked against the positions
     the vector was encoded from (oracle/pyref.ef_encode, the restatement of sdsl's sd_vector layout)."""
@@ -942,6 +942,22 @@ def test_gzip_sizes_when_a_wavefront_takes_many_reads(api, oracle_lib):
         assert bad.size == 0, (with_n, bad[:10], sizes[bad[:10]], want[bad[:10]])
     g.destroy()
     oidx.free()
+
+
+def test_bin_popcounts_of_a_large_index(api):
+    """chn_index_bin_popcounts (the loader's last self-check) on an index large enough that every thread of the kernel walks more than
+    255 words of its column (its byte-sliced accumulators are emptied on the way): 2^28 + 777 rows of one word, against numpy"""
+    S = (1 << 28) + 777
+    g = api.Index(api.make_desc(5, S, [0, 1, 0, 1, 0], 2, 0))
+    try:
+        g.synth_fill(43, 0.215)
+        pc = g.bin_popcounts()
+        w = g.download()
+        want = np.array([int(((w >> np.uint64(b)) & np.uint64(1)).sum()) for b in range(5)], np.uint64)
+        assert np.array_equal(pc[:5], want) and not pc[5:].any() and not (w >> np.uint64(5)).any()
+        assert 0.2 * S < want.min() and want.max() < 0.23 * S
+    finally:
+        g.destroy()
 
 
 def test_gather_roof_is_a_plausible_rate(api, oracle_lib):
